@@ -1,0 +1,108 @@
+/*
+ * mjbatch.h — C ABI of the MI355X-native batched MuJoCo step/rollout engine.
+ *
+ * This is the drop-in boundary for the reference's per-step physics path.  The
+ * reference (pure Python) reaches its physics through the pybind11 surface of the
+ * third-party `mujoco` package (stub: reference mujoco_template/mujoco.pyi:1-75);
+ * each entry point below names the reference call site it replaces.  Handles are
+ * opaque, arguments are plain pointers and sizes, every function returns 0 on
+ * success or a negative status and leaves a message for mjb_last_error().
+ * All functions on one mjbData are NOT re-entrant (reference semantics are
+ * single-threaded); launches go to the stream set with mjb_set_stream().
+ *
+ * There is no CPU fallback: without a HIP device mjb_data_create() fails.
+ */
+#ifndef MJBATCH_H
+#define MJBATCH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mjbModel mjbModel;
+typedef struct mjbData mjbData;
+typedef struct mjbObsSpec mjbObsSpec;
+
+#define MJB_OK 0
+#define MJB_ERR_ARG (-1)     /* bad argument / unknown name        -> ConfigError      */
+#define MJB_ERR_MODEL (-2)   /* model table rejected                -> ValueError       */
+#define MJB_ERR_DEVICE (-3)  /* HIP error / no device               -> TemplateError    */
+#define MJB_ERR_LOOKUP (-4)  /* index out of range                  -> NameLookupError  */
+
+#define MJB_F32 0
+#define MJB_F64 1
+
+/* ctrl source of a fused rollout */
+#define MJB_CTRL_KEEP 0    /* use data.ctrl as is (host controller wrote it)  */
+#define MJB_CTRL_ZERO 1    /* ZeroController, reference controllers.py:12-25 */
+#define MJB_CTRL_RANDOM 2  /* uniform random ctrl, Philox(seed; env, step, actuator) */
+
+const char* mjb_last_error(void);
+int mjb_device_count(void);
+
+/* ---- model: replaces MjModel.from_xml_* (reference model.py:22-37).  The XML is compiled on the
+ * host by mujoco_template_amd/mjcf.py; the compiled model crosses the ABI as a table of named
+ * arrays (dtype 0 = float64, 1 = int32) whose names follow mjModel. ---- */
+int mjb_model_create(int nfield, const char* const* names, const void* const* ptrs, const int* dtypes,
+                     const long* counts, mjbModel** out);
+void mjb_model_free(mjbModel* m);
+/* model.opt.disableactuator bit mask, reference model.py:88-93 */
+int mjb_model_set_disableactuator(mjbModel* m, int mask);
+/* solver knobs (mjOption.iterations / tolerance) */
+int mjb_model_set_solver(mjbModel* m, int iterations, double tolerance);
+
+/* ---- data: replaces MjData(model) (reference model.py:16-19) for `batch` independent replicas.
+ * dtype: MJB_F32 (product path) or MJB_F64.  lanes: lanes per environment (8, 16, 64; 0 = auto).
+ * nconmax / nefcmax: per-environment contact / constraint-row caps held in LDS (0 = default).
+ * env0: global index of this shard's first environment (keeps random ctrl shard-invariant). ---- */
+int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, int nefcmax, int device, int env0, mjbData** out);
+void mjb_data_free(mjbData* d);
+int mjb_set_stream(mjbData* d, void* hip_stream);
+int mjb_sync(mjbData* d);
+int mjb_data_info(mjbData* d, int* batch, int* dtype, int* lanes, int* nconmax, int* nefcmax, int* lds_bytes_per_env);
+
+/* device pointer of a [batch, n] state array: qpos qvel ctrl qacc qacc_warmstart (dtype of the data),
+ * time (float64 [batch]), xpos xquat xipos site_xpos geom_xpos subtree_com sensordata, counters (int32 [batch, 8]) */
+int mjb_array_ptr(mjbData* d, const char* name, void** dev_ptr, long* per_env, int* dtype);
+/* host <-> device copies with conversion to/from float64 (state snapshot/restore, reference state_utils.py:9-31) */
+int mjb_get_array(mjbData* d, const char* name, double* host_out);
+int mjb_set_array(mjbData* d, const char* name, const double* host_in);
+int mjb_get_counters(mjbData* d, int* host_out /* [batch, 8] */);
+
+/* mj_resetData / mj_resetDataKeyframe (reference model.py:59-71); key < 0 = qpos0 */
+int mjb_reset(mjbData* d, int key);
+/* mj_forward (reference model.py:53-54): fills qacc and the kinematic outputs */
+int mjb_forward(mjbData* d);
+/* nstep x mj_step (reference model.py:56-57, env.py:190), ctrl taken from data.ctrl */
+int mjb_step(mjbData* d, int nstep);
+/* fused rollout = the body of runtime.iterate_passive (reference runtime.py:631-663) for a device-side
+ * controller: nstep x [ctrl <- mode, mj_step]; when spec != NULL the flat observation of every
+ * `obs_every`-th step is written to obs_out_dev[(nstep/obs_every), batch, dim] (dtype of the data). */
+int mjb_rollout(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned step0, double ctrl_scale,
+                const mjbObsSpec* spec, void* obs_out_dev, int obs_every);
+
+/* ---- observations: ObservationExtractor.__call__ with as_dict=False (reference observations.py:98-174) ---- */
+int mjb_obs_spec_create(mjbData* d, int flags, int nsite, const int* site_ids, int nbody, const int* body_ids,
+                        int ngeom, const int* geom_ids, int nsubtree, const int* subtree_ids, mjbObsSpec** out);
+void mjb_obs_spec_free(mjbObsSpec* s);
+int mjb_obs_dim(const mjbObsSpec* s);
+int mjb_obs_gather(mjbData* d, const mjbObsSpec* s, void* out_dev /* [batch, dim], dtype of the data */);
+
+/* ---- mjd_transitionFD (reference linearization.py:16-35): float64 on device.
+ * A_host [batch, 2nv, 2nv], B_host [batch, 2nv, nu], row-major ---- */
+int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, double* B_host);
+
+/* ---- mj_jacSite / mj_jacBody / mj_jacBodyCom / mj_jacSubtreeCom (reference jacobians.py:44-79).
+ * kinds[i]: 0 site, 1 body, 2 bodycom, 3 subtreecom.  jacp/jacr host [batch, nreq, 3, nv] float64 (jacr may be NULL) ---- */
+int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp_host, double* jacr_host);
+
+/* per-phase dumps of the last mjb_forward for parity tests: name in
+ * qM qfrc_bias qfrc_passive qfrc_actuator qacc_smooth qfrc_constraint efc_J efc_aref efc_D efc_pos efc_force con cdof cinert cvel (float64 out)
+ * and efc_type (int32 out).  Call mjb_debug_forward() first. */
+int mjb_debug_forward(mjbData* d);
+int mjb_debug_get(mjbData* d, const char* name, void* host_out, long capacity_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

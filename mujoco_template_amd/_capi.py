@@ -1,0 +1,288 @@
+"""ctypes binding of ``libmjbatch.so`` (C ABI: ``include/mjbatch.h``) and the thin
+:class:`BatchSim` object the Python front (``model.py`` / ``env.py``) dispatches through.
+
+There is no CPU fallback: if the HIP library is missing or no device is
+visible, construction raises :class:`~mujoco_template_amd.exceptions.TemplateError`.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Sequence
+
+import numpy as np
+
+from ._pack import PackedTable
+from .exceptions import ConfigError, NameLookupError, TemplateError
+from .mjcf import CompiledModel
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmjbatch.so")
+_LIB: ctypes.CDLL | None = None
+
+MJB_F32, MJB_F64 = 0, 1
+CTRL_KEEP, CTRL_ZERO, CTRL_RANDOM = 0, 1, 2
+COUNTER_NAMES = ("ncon", "nefc", "solver_niter", "con_dropped", "efc_dropped", "warn_badqpos", "warn_badqvel", "warn_badqacc")
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP sources in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc, "-j6"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise TemplateError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the batched engine has no CPU fallback)")
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): import it first so both share one HIP runtime
+    import torch  # noqa: F401
+
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, ci, cd, cu, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_long
+    pvp = ctypes.POINTER(ctypes.c_void_p)
+    pci = ctypes.POINTER(ctypes.c_int)
+    L.mjb_last_error.restype = ctypes.c_char_p
+    L.mjb_device_count.restype = ci
+    L.mjb_model_create.argtypes = [ci, vp, vp, vp, vp, pvp]
+    L.mjb_model_free.argtypes = [vp]
+    L.mjb_model_set_disableactuator.argtypes = [vp, ci]
+    L.mjb_model_set_solver.argtypes = [vp, ci, cd]
+    L.mjb_data_create.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, pvp]
+    L.mjb_data_free.argtypes = [vp]
+    L.mjb_set_stream.argtypes = [vp, vp]
+    L.mjb_sync.argtypes = [vp]
+    L.mjb_data_info.argtypes = [vp, pci, pci, pci, pci, pci, pci]
+    L.mjb_array_ptr.argtypes = [vp, ctypes.c_char_p, pvp, ctypes.POINTER(cl), pci]
+    L.mjb_get_array.argtypes = [vp, ctypes.c_char_p, vp]
+    L.mjb_set_array.argtypes = [vp, ctypes.c_char_p, vp]
+    L.mjb_get_counters.argtypes = [vp, vp]
+    L.mjb_reset.argtypes = [vp, ci]
+    L.mjb_forward.argtypes = [vp]
+    L.mjb_step.argtypes = [vp, ci]
+    L.mjb_rollout.argtypes = [vp, ci, ci, cu, cu, cd, vp, vp, ci]
+    L.mjb_obs_spec_create.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci, vp, pvp]
+    L.mjb_obs_spec_free.argtypes = [vp]
+    L.mjb_obs_dim.argtypes = [vp]
+    L.mjb_obs_gather.argtypes = [vp, vp, vp]
+    L.mjb_transition_fd.argtypes = [vp, cd, ci, vp, vp]
+    L.mjb_jac.argtypes = [vp, ci, vp, vp, vp, vp]
+    L.mjb_debug_forward.argtypes = [vp]
+    L.mjb_debug_get.argtypes = [vp, ctypes.c_char_p, vp, cl]
+    for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
+                 "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
+                 "mjb_forward", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
+                 "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get"):
+        getattr(L, name).restype = ci
+    _LIB = L
+    return L
+
+
+def _check(rc: int) -> None:
+    """Map C status codes onto the reference's exception hierarchy (exceptions.py:4-21)."""
+    if rc == 0:
+        return
+    msg = load_library().mjb_last_error().decode()
+    if rc == -1:
+        raise ConfigError(msg)
+    if rc == -2:
+        raise ValueError(msg)
+    if rc == -4:
+        raise NameLookupError(msg)
+    raise TemplateError(msg)
+
+
+class _CudaArray:
+    """``__cuda_array_interface__`` shim so torch can wrap library-owned device memory zero-copy."""
+
+    def __init__(self, ptr: int, shape: tuple[int, ...], typestr: str, owner: object):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+        self._owner = owner
+
+
+def _ids(seq: Sequence[int]):
+    arr = np.ascontiguousarray(np.asarray(list(seq), dtype=np.int32))
+    return arr, (arr.ctypes.data if arr.size else None)
+
+
+class ObsSpecHandle:
+    def __init__(self, sim: "BatchSim", flags: int, site_ids, body_ids, geom_ids, subtree_ids):
+        L = load_library()
+        self.sim = sim
+        self.ptr = ctypes.c_void_p()
+        s, sp = _ids(site_ids); b, bp = _ids(body_ids); g, gp = _ids(geom_ids); t, tp = _ids(subtree_ids)
+        _check(L.mjb_obs_spec_create(sim.ptr, flags, s.size, sp, b.size, bp, g.size, gp, t.size, tp, ctypes.byref(self.ptr)))
+        self.dim = int(L.mjb_obs_dim(self.ptr))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load_library().mjb_obs_spec_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class DeviceModel:
+    """Handle of ``mjbModel`` (host copy of the compiled model inside the library)."""
+
+    def __init__(self, compiled: CompiledModel):
+        L = load_library()
+        self.compiled = compiled
+        self._packed = PackedTable(compiled)
+        p = self._packed
+        self.ptr = ctypes.c_void_p()
+        _check(L.mjb_model_create(p.n, ctypes.cast(p.names, ctypes.c_void_p), ctypes.cast(p.ptrs, ctypes.c_void_p),
+                                  ctypes.cast(p.dtypes, ctypes.c_void_p), ctypes.cast(p.counts, ctypes.c_void_p), ctypes.byref(self.ptr)))
+
+    def set_disableactuator(self, mask: int) -> None:
+        _check(load_library().mjb_model_set_disableactuator(self.ptr, int(mask)))
+
+    def set_solver(self, iterations: int, tolerance: float) -> None:
+        _check(load_library().mjb_model_set_solver(self.ptr, int(iterations), float(tolerance)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load_library().mjb_model_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class BatchSim:
+    """``batch`` replicas of one model resident on one GPU (handle of ``mjbData``)."""
+
+    def __init__(self, model: DeviceModel, batch: int, *, dtype: str = "float32", lanes: int = 0, nconmax: int = 0,
+                 nefcmax: int = 0, device: int = 0, env0: int = 0):
+        L = load_library()
+        if dtype not in ("float32", "float64"):
+            raise ConfigError("dtype must be 'float32' or 'float64'")
+        self.model = model
+        self.batch = int(batch)
+        self.dtype = dtype
+        self.np_dtype = np.float32 if dtype == "float32" else np.float64
+        self.device = int(device)
+        self.ptr = ctypes.c_void_p()
+        _check(L.mjb_data_create(model.ptr, self.batch, MJB_F32 if dtype == "float32" else MJB_F64, int(lanes), int(nconmax),
+                                 int(nefcmax), self.device, int(env0), ctypes.byref(self.ptr)))
+        info = [ctypes.c_int() for _ in range(6)]
+        _check(L.mjb_data_info(self.ptr, *[ctypes.byref(x) for x in info]))
+        self.lanes, self.nconmax, self.nefcmax, self.lds_bytes_per_env = info[2].value, info[3].value, info[4].value, info[5].value
+
+    # -- plumbing -----------------------------------------------------------------
+    def set_stream(self, stream_handle: int) -> None:
+        _check(load_library().mjb_set_stream(self.ptr, ctypes.c_void_p(stream_handle)))
+
+    def use_torch_stream(self) -> None:
+        import torch
+
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self) -> None:
+        _check(load_library().mjb_sync(self.ptr))
+
+    def array_ptr(self, name: str) -> tuple[int, int, int]:
+        p, n, dt = ctypes.c_void_p(), ctypes.c_long(), ctypes.c_int()
+        _check(load_library().mjb_array_ptr(self.ptr, name.encode(), ctypes.byref(p), ctypes.byref(n), ctypes.byref(dt)))
+        return int(p.value or 0), int(n.value), int(dt.value)
+
+    def torch_view(self, name: str):
+        """Zero-copy torch tensor [batch, n] over the library-owned device array."""
+        import torch
+
+        ptr, n, dt = self.array_ptr(name)
+        typestr = {0: "<f4", 1: "<f8", 2: "<i4"}[dt]
+        if n == 0 or ptr == 0:
+            return torch.zeros((self.batch, 0), device=f"cuda:{self.device}")
+        return torch.as_tensor(_CudaArray(ptr, (self.batch, n), typestr, self), device=f"cuda:{self.device}")
+
+    def get(self, name: str) -> np.ndarray:
+        _, n, _ = self.array_ptr(name)
+        out = np.zeros((self.batch, n), dtype=np.float64)
+        if n:
+            _check(load_library().mjb_get_array(self.ptr, name.encode(), out.ctypes.data))
+        return out
+
+    def set(self, name: str, value: np.ndarray) -> None:
+        _, n, _ = self.array_ptr(name)
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64).reshape(-1, n) if n else np.zeros((self.batch, 0)), (self.batch, n)))
+        if n:
+            _check(load_library().mjb_set_array(self.ptr, name.encode(), arr.ctypes.data))
+
+    def counters(self) -> dict[str, np.ndarray]:
+        out = np.zeros((self.batch, 8), dtype=np.int32)
+        _check(load_library().mjb_get_counters(self.ptr, out.ctypes.data))
+        return {k: out[:, i] for i, k in enumerate(COUNTER_NAMES)}
+
+    # -- physics ------------------------------------------------------------------
+    def reset(self, key: int = -1) -> None:
+        _check(load_library().mjb_reset(self.ptr, int(key)))
+
+    def forward(self) -> None:
+        _check(load_library().mjb_forward(self.ptr))
+
+    def step(self, nstep: int = 1) -> None:
+        _check(load_library().mjb_step(self.ptr, int(nstep)))
+
+    def rollout(self, nstep: int, ctrl_mode: int = CTRL_KEEP, seed: int = 0, step0: int = 0, ctrl_scale: float = 1.0,
+                obs_spec: ObsSpecHandle | None = None, obs_out_ptr: int = 0, obs_every: int = 0) -> None:
+        _check(load_library().mjb_rollout(self.ptr, int(nstep), int(ctrl_mode), int(seed) & 0xFFFFFFFF, int(step0) & 0xFFFFFFFF,
+                                          float(ctrl_scale), obs_spec.ptr if obs_spec else None,
+                                          ctypes.c_void_p(obs_out_ptr) if obs_out_ptr else None, int(obs_every)))
+
+    def make_obs_spec(self, flags: int, site_ids=(), body_ids=(), geom_ids=(), subtree_ids=()) -> ObsSpecHandle:
+        return ObsSpecHandle(self, flags, site_ids, body_ids, geom_ids, subtree_ids)
+
+    def obs_gather(self, spec: ObsSpecHandle, out_ptr: int) -> None:
+        _check(load_library().mjb_obs_gather(self.ptr, spec.ptr, ctypes.c_void_p(out_ptr)))
+
+    def transition_fd(self, eps: float = 1e-6, centered: bool = True) -> tuple[np.ndarray, np.ndarray]:
+        m = self.model.compiled
+        A = np.zeros((self.batch, 2 * m.nv, 2 * m.nv))
+        B = np.zeros((self.batch, 2 * m.nv, max(m.nu, 1)))
+        Bv = np.zeros((self.batch, 2 * m.nv, m.nu))
+        _check(load_library().mjb_transition_fd(self.ptr, float(eps), int(bool(centered)), A.ctypes.data, (Bv if m.nu else B).ctypes.data))
+        return A, Bv
+
+    def jac(self, kinds: Sequence[int], ids: Sequence[int]) -> tuple[np.ndarray, np.ndarray]:
+        m = self.model.compiled
+        k, kp = _ids(kinds); i, ip = _ids(ids)
+        jp = np.zeros((self.batch, k.size, 3, m.nv))
+        jr = np.zeros((self.batch, k.size, 3, m.nv))
+        _check(load_library().mjb_jac(self.ptr, k.size, kp, ip, jp.ctypes.data, jr.ctypes.data))
+        return jp, jr
+
+    def debug_forward(self) -> None:
+        _check(load_library().mjb_debug_forward(self.ptr))
+
+    def debug_get(self, name: str) -> np.ndarray:
+        m = self.model.compiled
+        nv = m.nv
+        per = {"qM": nv * nv, "qfrc_bias": nv, "qfrc_passive": nv, "qfrc_actuator": nv, "qacc_smooth": nv, "qfrc_constraint": nv,
+               "efc_J": self.nefcmax * nv, "efc_aref": self.nefcmax, "efc_D": self.nefcmax, "efc_pos": self.nefcmax,
+               "efc_force": self.nefcmax, "con": self.nconmax * 14, "cdof": 6 * nv, "cinert": 10 * m.nbody, "cvel": 6 * m.nbody,
+               "efc_type": self.nefcmax}[name]
+        out = np.zeros((self.batch, per), dtype=np.int32 if name == "efc_type" else np.float64)
+        _check(load_library().mjb_debug_get(self.ptr, name.encode(), out.ctypes.data, out.size))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load_library().mjb_data_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+__all__ = ["BatchSim", "DeviceModel", "ObsSpecHandle", "build_library", "load_library", "CTRL_KEEP", "CTRL_ZERO", "CTRL_RANDOM"]

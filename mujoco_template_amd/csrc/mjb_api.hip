@@ -1,0 +1,505 @@
+// mjb_api.hip — host side of the C ABI declared in include/mjbatch.h.
+// Owns device memory (SoA [batch, dof] state in HBM, model constants), launches the
+// kernels of mjb_kernels.hpp on the caller's HIP stream.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mjbatch.h"
+#include "mjb_host.hpp"
+#include "mjb_kernels.hpp"
+
+using namespace mjb;
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                           \
+  do {                                                                                                         \
+    hipError_t e_ = (expr);                                                                                    \
+    if (e_ != hipSuccess) return fail(MJB_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+struct DevAlloc {
+  std::vector<void*> ptrs;
+  bool ok = true;
+  template <typename X> const X* put(const std::vector<X>& v) {
+    size_t n = v.size() ? v.size() : 1;
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(X)) != hipSuccess) { ok = false; return nullptr; }
+    ptrs.push_back(p);
+    if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(X), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    return (const X*)p;
+  }
+  const float* putf(const std::vector<float>& v) { return put(v); }
+  const double* putf(const std::vector<double>& v) { return put(v); }
+  const int* puti(const std::vector<int>& v) { return put(v); }
+  const unsigned long long* putu(const std::vector<unsigned long long>& v) { return put(v); }
+  void release() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+};
+
+struct ArrayInfo { void* ptr; long per_env; int kind; };  // kind: 0 = data dtype, 1 = float64, 2 = int32
+}  // namespace
+
+struct mjbModel {
+  HostModel h;
+  int disableactuator;
+  int iterations;
+  double tolerance;
+};
+
+struct mjbObsSpec {
+  ObsSpecDev dev;
+  std::vector<void*> owned;
+};
+
+struct mjbData {
+  mjbModel* model;
+  int batch, dtype, G, ncon_max, nefc_max, device, env0;
+  hipStream_t stream;
+  DevAlloc alloc;
+  DevModel<float> mf;
+  DevModel<double> md;
+  Lay Lf, Ld;
+  DevData<float> df;
+  DevData<double> dd;
+  std::map<std::string, ArrayInfo> arrays;
+  std::vector<void*> owned;
+  // debug dumps
+  bool dbg_ready = false;
+  DevDebug<float> dbgf;
+  DevDebug<double> dbgd;
+  std::map<std::string, ArrayInfo> dbg_arrays;
+  // fd / jac scratch
+  double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
+  int* fd_valid = nullptr;
+};
+
+namespace {
+template <typename X> int dev_alloc(mjbData* d, X** out, size_t n) {
+  void* p = nullptr;
+  if (n == 0) n = 1;
+  if (hipMalloc(&p, n * sizeof(X)) != hipSuccess) return -1;
+  if (hipMemset(p, 0, n * sizeof(X)) != hipSuccess) return -1;
+  d->owned.push_back(p);
+  *out = (X*)p;
+  return 0;
+}
+
+template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
+  const HostModel& h = d->model->h;
+  size_t B = (size_t)d->batch;
+  s.batch = d->batch;
+  int rc = 0;
+  rc |= dev_alloc(d, &s.qpos, B * h.nq); rc |= dev_alloc(d, &s.qvel, B * h.nv); rc |= dev_alloc(d, &s.ctrl, B * h.nu);
+  rc |= dev_alloc(d, &s.qacc, B * h.nv); rc |= dev_alloc(d, &s.qacc_warmstart, B * h.nv); rc |= dev_alloc(d, &s.time, B);
+  rc |= dev_alloc(d, &s.xpos, B * h.nbody * 3); rc |= dev_alloc(d, &s.xquat, B * h.nbody * 4); rc |= dev_alloc(d, &s.xipos, B * h.nbody * 3);
+  rc |= dev_alloc(d, &s.site_xpos, B * h.nsite * 3); rc |= dev_alloc(d, &s.geom_xpos, B * h.ngeom * 3);
+  rc |= dev_alloc(d, &s.subtree_com, B * h.nbody * 3); rc |= dev_alloc(d, &s.sensordata, B * h.nsensordata);
+  rc |= dev_alloc(d, &s.counters, B * CNT_N);
+  if (rc) return -1;
+  auto& A = d->arrays;
+  A["qpos"] = {s.qpos, h.nq, 0}; A["qvel"] = {s.qvel, h.nv, 0}; A["ctrl"] = {s.ctrl, h.nu, 0}; A["qacc"] = {s.qacc, h.nv, 0};
+  A["qacc_warmstart"] = {s.qacc_warmstart, h.nv, 0}; A["time"] = {s.time, 1, 1};
+  A["xpos"] = {s.xpos, h.nbody * 3L, 0}; A["xquat"] = {s.xquat, h.nbody * 4L, 0}; A["xipos"] = {s.xipos, h.nbody * 3L, 0};
+  A["site_xpos"] = {s.site_xpos, h.nsite * 3L, 0}; A["geom_xpos"] = {s.geom_xpos, h.ngeom * 3L, 0};
+  A["subtree_com"] = {s.subtree_com, h.nbody * 3L, 0}; A["sensordata"] = {s.sensordata, h.nsensordata, 0};
+  A["counters"] = {s.counters, CNT_N, 2};
+  return 0;
+}
+
+template <typename TS> int alloc_debug(mjbData* d, DevDebug<TS>& g) {
+  const HostModel& h = d->model->h;
+  size_t B = (size_t)d->batch, nv = h.nv, ne = d->nefc_max, nc = d->ncon_max;
+  int rc = 0;
+  rc |= dev_alloc(d, &g.qM, B * nv * nv); rc |= dev_alloc(d, &g.qfrc_bias, B * nv); rc |= dev_alloc(d, &g.qfrc_passive, B * nv);
+  rc |= dev_alloc(d, &g.qfrc_actuator, B * nv); rc |= dev_alloc(d, &g.qacc_smooth, B * nv); rc |= dev_alloc(d, &g.qfrc_constraint, B * nv);
+  rc |= dev_alloc(d, &g.efc_J, B * ne * nv); rc |= dev_alloc(d, &g.efc_aref, B * ne); rc |= dev_alloc(d, &g.efc_D, B * ne);
+  rc |= dev_alloc(d, &g.efc_pos, B * ne); rc |= dev_alloc(d, &g.efc_force, B * ne); rc |= dev_alloc(d, &g.con, B * nc * CON_STRIDE);
+  rc |= dev_alloc(d, &g.cdof, B * 6 * nv); rc |= dev_alloc(d, &g.cinert, B * 10 * h.nbody); rc |= dev_alloc(d, &g.cvel, B * 6 * h.nbody);
+  rc |= dev_alloc(d, &g.efc_type, B * ne);
+  if (rc) return -1;
+  auto& A = d->dbg_arrays;
+  A["qM"] = {g.qM, (long)(nv * nv), 0}; A["qfrc_bias"] = {g.qfrc_bias, (long)nv, 0}; A["qfrc_passive"] = {g.qfrc_passive, (long)nv, 0};
+  A["qfrc_actuator"] = {g.qfrc_actuator, (long)nv, 0}; A["qacc_smooth"] = {g.qacc_smooth, (long)nv, 0}; A["qfrc_constraint"] = {g.qfrc_constraint, (long)nv, 0};
+  A["efc_J"] = {g.efc_J, (long)(ne * nv), 0}; A["efc_aref"] = {g.efc_aref, (long)ne, 0}; A["efc_D"] = {g.efc_D, (long)ne, 0};
+  A["efc_pos"] = {g.efc_pos, (long)ne, 0}; A["efc_force"] = {g.efc_force, (long)ne, 0}; A["con"] = {g.con, (long)(nc * CON_STRIDE), 0};
+  A["cdof"] = {g.cdof, (long)(6 * nv), 0}; A["cinert"] = {g.cinert, 10L * h.nbody, 0}; A["cvel"] = {g.cvel, 6L * h.nbody, 0};
+  A["efc_type"] = {g.efc_type, (long)ne, 2};
+  return 0;
+}
+
+void refresh_options(mjbData* d) {
+  d->mf.disableactuator = d->md.disableactuator = d->model->disableactuator;
+  d->mf.iterations = d->md.iterations = d->model->iterations;
+  d->md.tolerance = d->model->tolerance;
+  float tol = (float)d->model->tolerance;
+  d->mf.tolerance = tol < 1e-6f ? 1e-6f : tol;
+}
+
+int launch(mjbData* d, const StepArgs& a, const ObsSpecDev& obs, void* obs_out, bool debug) {
+  refresh_options(d);
+  hipError_t e;
+  if (d->dtype == MJB_F32) {
+    DevDebug<float> none; std::memset(&none, 0, sizeof(none));
+    e = launch_step<float, float>(d->G, d->mf, d->Lf, d->df, debug ? d->dbgf : none, a, obs, (float*)obs_out, d->stream);
+  } else {
+    DevDebug<double> none; std::memset(&none, 0, sizeof(none));
+    e = launch_step<double, double>(d->G, d->md, d->Ld, d->dd, debug ? d->dbgd : none, a, obs, (double*)obs_out, d->stream);
+  }
+  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+  return MJB_OK;
+}
+
+int copy_out(mjbData* d, const ArrayInfo& ai, double* host_out) {
+  size_t n = (size_t)d->batch * ai.per_env;
+  if (n == 0) return MJB_OK;
+  HIPCHK(hipStreamSynchronize(d->stream));
+  if (ai.kind == 1 || (ai.kind == 0 && d->dtype == MJB_F64)) {
+    HIPCHK(hipMemcpy(host_out, ai.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
+  } else if (ai.kind == 0) {
+    std::vector<float> tmp(n);
+    HIPCHK(hipMemcpy(tmp.data(), ai.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) host_out[i] = (double)tmp[i];
+  } else return fail(MJB_ERR_ARG, "integer array requested as float64");
+  return MJB_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* mjb_last_error(void) { return g_err.c_str(); }
+
+int mjb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mjb_model_create(int nfield, const char* const* names, const void* const* ptrs, const int* dtypes, const long* counts, mjbModel** out) {
+  if (!out) return fail(MJB_ERR_ARG, "out is NULL");
+  Table t{nfield, names, ptrs, dtypes, counts};
+  mjbModel* m = new mjbModel();
+  std::string err;
+  if (!m->h.load(t, err)) { delete m; return fail(MJB_ERR_MODEL, err); }
+  m->disableactuator = m->h.disableactuator;
+  m->iterations = m->h.iterations;
+  m->tolerance = m->h.tolerance;
+  *out = m;
+  return MJB_OK;
+}
+
+void mjb_model_free(mjbModel* m) { delete m; }
+
+int mjb_model_set_disableactuator(mjbModel* m, int mask) { if (!m) return fail(MJB_ERR_ARG, "model is NULL"); m->disableactuator = mask; return MJB_OK; }
+int mjb_model_set_solver(mjbModel* m, int iterations, double tolerance) {
+  if (!m || iterations < 1 || !(tolerance >= 0)) return fail(MJB_ERR_ARG, "bad solver options");
+  m->iterations = iterations; m->tolerance = tolerance;
+  return MJB_OK;
+}
+
+int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, int nefcmax, int device, int env0, mjbData** out) {
+  if (!m || !out) return fail(MJB_ERR_ARG, "model/out is NULL");
+  if (batch < 1) return fail(MJB_ERR_ARG, "batch must be >= 1");
+  if (dtype != MJB_F32 && dtype != MJB_F64) return fail(MJB_ERR_ARG, "dtype must be MJB_F32 or MJB_F64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(MJB_ERR_DEVICE, "no HIP device: the batched engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(MJB_ERR_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  const HostModel& h = m->h;
+  if (lanes == 0) lanes = h.nv <= 4 ? 8 : (h.nv <= 16 ? 16 : 64);
+  if (lanes != 8 && lanes != 16 && lanes != 64) return fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64");
+  mjbData* d = new mjbData();
+  d->model = m; d->batch = batch; d->dtype = dtype; d->G = lanes; d->device = device; d->env0 = env0; d->stream = nullptr;
+  d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 48 ? h.ncon_alloc : 48);
+  d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 128 ? h.nefc_alloc : 128);
+  if (d->ncon_max < 1) d->ncon_max = 1;
+  if (d->nefc_max < 1) d->nefc_max = 1;
+  fill_dev_model<float>(h, d->alloc, d->ncon_max, d->nefc_max, d->mf);
+  fill_dev_model<double>(h, d->alloc, d->ncon_max, d->nefc_max, d->md);
+  if (!d->alloc.ok) { mjb_data_free(d); return fail(MJB_ERR_DEVICE, "device allocation of the model failed"); }
+  d->Lf = make_layout(h, d->ncon_max, d->nefc_max, sizeof(float));
+  d->Ld = make_layout(h, d->ncon_max, d->nefc_max, sizeof(double));
+  size_t lds = (size_t)(64 / d->G) * (size_t)d->Ld.bytes;
+  if (lds > 160 * 1024) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "per-workgroup LDS %zu B exceeds 160 KiB (lower nconmax/nefcmax or use more lanes)", lds);
+    mjb_data_free(d);
+    return fail(MJB_ERR_ARG, buf);
+  }
+  std::memset(&d->df, 0, sizeof(d->df)); std::memset(&d->dd, 0, sizeof(d->dd));
+  int rc = dtype == MJB_F32 ? alloc_state(d, d->df) : alloc_state(d, d->dd);
+  if (rc) { mjb_data_free(d); return fail(MJB_ERR_DEVICE, "device allocation of the state failed"); }
+  *out = d;
+  int r = mjb_reset(d, -1);
+  if (r != MJB_OK) { mjb_data_free(d); *out = nullptr; return r; }
+  return MJB_OK;
+}
+
+void mjb_data_free(mjbData* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (void* p : d->owned) (void)hipFree(p);
+  d->alloc.release();
+  delete d;
+}
+
+int mjb_set_stream(mjbData* d, void* hip_stream) { if (!d) return fail(MJB_ERR_ARG, "data is NULL"); d->stream = (hipStream_t)hip_stream; return MJB_OK; }
+int mjb_sync(mjbData* d) { if (!d) return fail(MJB_ERR_ARG, "data is NULL"); HIPCHK(hipStreamSynchronize(d->stream)); return MJB_OK; }
+
+int mjb_data_info(mjbData* d, int* batch, int* dtype, int* lanes, int* nconmax, int* nefcmax, int* lds_bytes_per_env) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (batch) *batch = d->batch;
+  if (dtype) *dtype = d->dtype;
+  if (lanes) *lanes = d->G;
+  if (nconmax) *nconmax = d->ncon_max;
+  if (nefcmax) *nefcmax = d->nefc_max;
+  if (lds_bytes_per_env) *lds_bytes_per_env = d->dtype == MJB_F32 ? d->Lf.bytes : d->Ld.bytes;
+  return MJB_OK;
+}
+
+int mjb_array_ptr(mjbData* d, const char* name, void** dev_ptr, long* per_env, int* dtype) {
+  if (!d || !name) return fail(MJB_ERR_ARG, "data/name is NULL");
+  auto it = d->arrays.find(name);
+  if (it == d->arrays.end()) return fail(MJB_ERR_ARG, std::string("unknown array: ") + name);
+  if (dev_ptr) *dev_ptr = it->second.ptr;
+  if (per_env) *per_env = it->second.per_env;
+  if (dtype) *dtype = it->second.kind == 0 ? d->dtype : (it->second.kind == 1 ? MJB_F64 : 2);
+  return MJB_OK;
+}
+
+int mjb_get_array(mjbData* d, const char* name, double* host_out) {
+  if (!d || !name || !host_out) return fail(MJB_ERR_ARG, "NULL argument");
+  auto it = d->arrays.find(name);
+  if (it == d->arrays.end()) return fail(MJB_ERR_ARG, std::string("unknown array: ") + name);
+  HIPCHK(hipSetDevice(d->device));
+  return copy_out(d, it->second, host_out);
+}
+
+int mjb_set_array(mjbData* d, const char* name, const double* host_in) {
+  if (!d || !name || !host_in) return fail(MJB_ERR_ARG, "NULL argument");
+  auto it = d->arrays.find(name);
+  if (it == d->arrays.end()) return fail(MJB_ERR_ARG, std::string("unknown array: ") + name);
+  const ArrayInfo& ai = it->second;
+  size_t n = (size_t)d->batch * ai.per_env;
+  if (n == 0) return MJB_OK;
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  if (ai.kind == 1 || (ai.kind == 0 && d->dtype == MJB_F64)) {
+    HIPCHK(hipMemcpy(ai.ptr, host_in, n * sizeof(double), hipMemcpyHostToDevice));
+  } else if (ai.kind == 0) {
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = (float)host_in[i];
+    HIPCHK(hipMemcpy(ai.ptr, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  } else return fail(MJB_ERR_ARG, "integer arrays are read-only");
+  return MJB_OK;
+}
+
+int mjb_get_counters(mjbData* d, int* host_out) {
+  if (!d || !host_out) return fail(MJB_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  HIPCHK(hipMemcpy(host_out, d->arrays["counters"].ptr, (size_t)d->batch * CNT_N * sizeof(int), hipMemcpyDeviceToHost));
+  return MJB_OK;
+}
+
+int mjb_reset(mjbData* d, int key) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  const HostModel& h = d->model->h;
+  if (key >= h.nkey) return fail(MJB_ERR_LOOKUP, "keyframe index out of range");
+  HIPCHK(hipSetDevice(d->device));
+  int threads = 256, grid = (d->batch + threads - 1) / threads;
+  double time = key >= 0 ? h.D("key_time")[key] : 0.0;
+  if (d->dtype == MJB_F32) {
+    const float* qp = key >= 0 ? d->mf.key_qpos + (size_t)key * h.nq : d->mf.qpos0;
+    const float* qv = key >= 0 ? d->mf.key_qvel + (size_t)key * h.nv : nullptr;
+    const float* cu = key >= 0 ? d->mf.key_ctrl + (size_t)key * h.nu : nullptr;
+    hipLaunchKernelGGL(k_reset<float>, dim3(grid), dim3(threads), 0, d->stream, d->df, h.nq, h.nv, h.nu, qp, qv, cu, time);
+  } else {
+    const double* qp = key >= 0 ? d->md.key_qpos + (size_t)key * h.nq : d->md.qpos0;
+    const double* qv = key >= 0 ? d->md.key_qvel + (size_t)key * h.nv : nullptr;
+    const double* cu = key >= 0 ? d->md.key_ctrl + (size_t)key * h.nu : nullptr;
+    hipLaunchKernelGGL(k_reset<double>, dim3(grid), dim3(threads), 0, d->stream, d->dd, h.nq, h.nv, h.nu, qp, qv, cu, time);
+  }
+  HIPCHK(hipGetLastError());
+  return MJB_OK;
+}
+
+static StepArgs make_args(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned step0, double scale, int mode) {
+  StepArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.nstep = nstep; a.ctrl_mode = ctrl_mode; a.seed = seed; a.step0 = step0; a.env0 = (unsigned)d->env0;
+  a.ctrl_scale = (float)scale; a.mode = mode; a.write_kin = 1; a.obs_every = 0;
+  return a;
+}
+
+int mjb_forward(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  HIPCHK(hipSetDevice(d->device));
+  ObsSpecDev none; std::memset(&none, 0, sizeof(none));
+  return launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, false);
+}
+
+int mjb_step(mjbData* d, int nstep) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (nstep < 1) return fail(MJB_ERR_ARG, "nstep must be >= 1");
+  HIPCHK(hipSetDevice(d->device));
+  ObsSpecDev none; std::memset(&none, 0, sizeof(none));
+  return launch(d, make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0), none, nullptr, false);
+}
+
+int mjb_rollout(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned step0, double ctrl_scale,
+                const mjbObsSpec* spec, void* obs_out_dev, int obs_every) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (nstep < 1) return fail(MJB_ERR_ARG, "nstep must be >= 1");
+  if (ctrl_mode < 0 || ctrl_mode > 2) return fail(MJB_ERR_ARG, "bad ctrl_mode");
+  HIPCHK(hipSetDevice(d->device));
+  StepArgs a = make_args(d, nstep, ctrl_mode, seed, step0, ctrl_scale, 0);
+  ObsSpecDev obs; std::memset(&obs, 0, sizeof(obs));
+  if (spec && obs_out_dev && obs_every > 0) { obs = spec->dev; a.obs_every = obs_every; }
+  return launch(d, a, obs, obs_out_dev, false);
+}
+
+int mjb_obs_spec_create(mjbData* d, int flags, int nsite, const int* site_ids, int nbody, const int* body_ids,
+                        int ngeom, const int* geom_ids, int nsubtree, const int* subtree_ids, mjbObsSpec** out) {
+  if (!d || !out) return fail(MJB_ERR_ARG, "NULL argument");
+  const HostModel& h = d->model->h;
+  for (int i = 0; i < nsite; i++) if (site_ids[i] < 0 || site_ids[i] >= h.nsite) return fail(MJB_ERR_LOOKUP, "site id out of range");
+  for (int i = 0; i < nbody; i++) if (body_ids[i] < 0 || body_ids[i] >= h.nbody) return fail(MJB_ERR_LOOKUP, "body id out of range");
+  for (int i = 0; i < ngeom; i++) if (geom_ids[i] < 0 || geom_ids[i] >= h.ngeom) return fail(MJB_ERR_LOOKUP, "geom id out of range");
+  for (int i = 0; i < nsubtree; i++) if (subtree_ids[i] < 0 || subtree_ids[i] >= h.nbody) return fail(MJB_ERR_LOOKUP, "subtree body id out of range");
+  HIPCHK(hipSetDevice(d->device));
+  mjbObsSpec* s = new mjbObsSpec();
+  std::memset(&s->dev, 0, sizeof(s->dev));
+  auto up = [&](const int* ids, int n) -> const int* {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(int) * (n > 0 ? n : 1)) != hipSuccess) return nullptr;
+    s->owned.push_back(p);
+    if (n > 0) (void)hipMemcpy(p, ids, sizeof(int) * n, hipMemcpyHostToDevice);
+    return (const int*)p;
+  };
+  s->dev.flags = flags; s->dev.nsite = nsite; s->dev.nbody = nbody; s->dev.ngeom = ngeom; s->dev.nsubtree = nsubtree;
+  s->dev.site_ids = up(site_ids, nsite); s->dev.body_ids = up(body_ids, nbody); s->dev.geom_ids = up(geom_ids, ngeom); s->dev.subtree_ids = up(subtree_ids, nsubtree);
+  int dim = 3 * (nsite + nbody + ngeom + nsubtree);
+  if (flags & 1) dim += h.nq;
+  if (flags & 2) dim += h.nv;
+  if (flags & 4) dim += h.nu;
+  if (flags & 8) dim += h.nsensordata;
+  if (flags & 16) dim += 1;
+  s->dev.dim = dim;
+  *out = s;
+  return MJB_OK;
+}
+
+void mjb_obs_spec_free(mjbObsSpec* s) {
+  if (!s) return;
+  for (void* p : s->owned) (void)hipFree(p);
+  delete s;
+}
+
+int mjb_obs_dim(const mjbObsSpec* s) { return s ? s->dev.dim : -1; }
+
+int mjb_obs_gather(mjbData* d, const mjbObsSpec* s, void* out_dev) {
+  if (!d || !s || !out_dev) return fail(MJB_ERR_ARG, "NULL argument");
+  const HostModel& h = d->model->h;
+  HIPCHK(hipSetDevice(d->device));
+  if (d->dtype == MJB_F32)
+    hipLaunchKernelGGL(k_obs<float>, dim3(d->batch), dim3(64), 0, d->stream, d->df, h.nq, h.nv, h.nu, h.nbody, h.ngeom, h.nsite, h.nsensordata, s->dev, (float*)out_dev);
+  else
+    hipLaunchKernelGGL(k_obs<double>, dim3(d->batch), dim3(64), 0, d->stream, d->dd, h.nq, h.nv, h.nu, h.nbody, h.ngeom, h.nsite, h.nsensordata, s->dev, (double*)out_dev);
+  HIPCHK(hipGetLastError());
+  return MJB_OK;
+}
+
+int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, double* B_host) {
+  if (!d || !A_host || !B_host) return fail(MJB_ERR_ARG, "NULL argument");
+  if (!(eps > 0)) return fail(MJB_ERR_ARG, "eps must be > 0");
+  const HostModel& h = d->model->h;
+  HIPCHK(hipSetDevice(d->device));
+  refresh_options(d);
+  const int nin = 2 * h.nv + h.nu, ncol = 1 + 2 * nin, nx = 2 * h.nv;
+  size_t B = (size_t)d->batch;
+  if (!d->fd_y) {
+    if (dev_alloc(d, &d->fd_y, B * ncol * (h.nq + h.nv)) || dev_alloc(d, &d->fd_valid, B * ncol) ||
+        dev_alloc(d, &d->fd_A, B * nx * nx) || dev_alloc(d, &d->fd_B, B * nx * (h.nu > 0 ? h.nu : 1)))
+      return fail(MJB_ERR_DEVICE, "device allocation of FD scratch failed");
+  }
+  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G, d->md, d->Ld, d->df, ncol, eps, d->fd_y, d->fd_valid, d->stream)
+                                     : launch_fd<double, double>(d->G, d->md, d->Ld, d->dd, ncol, eps, d->fd_y, d->fd_valid, d->stream);
+  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("fd launch: ") + hipGetErrorString(e));
+  long nthreads = (long)B * nin;
+  hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, d->md, d->batch, ncol, centered, eps,
+                     (const double*)d->fd_y, (const int*)d->fd_valid, d->fd_A, d->fd_B);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(d->stream));
+  HIPCHK(hipMemcpy(A_host, d->fd_A, B * nx * nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (h.nu > 0) HIPCHK(hipMemcpy(B_host, d->fd_B, B * nx * h.nu * sizeof(double), hipMemcpyDeviceToHost));
+  return MJB_OK;
+}
+
+int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp_host, double* jacr_host) {
+  if (!d || !kinds || !ids || !jacp_host || nreq < 1) return fail(MJB_ERR_ARG, "bad argument");
+  const HostModel& h = d->model->h;
+  for (int i = 0; i < nreq; i++) {
+    if (kinds[i] < 0 || kinds[i] > 3) return fail(MJB_ERR_ARG, "jacobian kind must be 0..3");
+    int lim = kinds[i] == 0 ? h.nsite : h.nbody;
+    if (ids[i] < 0 || ids[i] >= lim) return fail(MJB_ERR_LOOKUP, "jacobian object id out of range");
+  }
+  HIPCHK(hipSetDevice(d->device));
+  size_t n = (size_t)d->batch * nreq * 3 * h.nv;
+  double *op = nullptr, *orr = nullptr; int *dk = nullptr, *di = nullptr;
+  HIPCHK(hipMalloc((void**)&op, sizeof(double) * (n ? n : 1)));
+  HIPCHK(hipMalloc((void**)&orr, sizeof(double) * (n ? n : 1)));
+  HIPCHK(hipMalloc((void**)&dk, sizeof(int) * nreq));
+  HIPCHK(hipMalloc((void**)&di, sizeof(int) * nreq));
+  HIPCHK(hipMemcpy(dk, kinds, sizeof(int) * nreq, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(di, ids, sizeof(int) * nreq, hipMemcpyHostToDevice));
+  hipError_t e = d->dtype == MJB_F32 ? launch_jac<double, float>(d->G, d->md, d->Ld, d->df, nreq, dk, di, op, orr, d->stream)
+                                     : launch_jac<double, double>(d->G, d->md, d->Ld, d->dd, nreq, dk, di, op, orr, d->stream);
+  int rc = MJB_OK;
+  if (e != hipSuccess) rc = fail(MJB_ERR_DEVICE, std::string("jac launch: ") + hipGetErrorString(e));
+  if (rc == MJB_OK && hipStreamSynchronize(d->stream) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac sync failed");
+  if (rc == MJB_OK && n) {
+    if (hipMemcpy(jacp_host, op, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac copy failed");
+    if (jacr_host && hipMemcpy(jacr_host, orr, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac copy failed");
+  }
+  (void)hipFree(op); (void)hipFree(orr); (void)hipFree(dk); (void)hipFree(di);
+  return rc;
+}
+
+int mjb_debug_forward(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  HIPCHK(hipSetDevice(d->device));
+  if (!d->dbg_ready) {
+    std::memset(&d->dbgf, 0, sizeof(d->dbgf)); std::memset(&d->dbgd, 0, sizeof(d->dbgd));
+    int rc = d->dtype == MJB_F32 ? alloc_debug(d, d->dbgf) : alloc_debug(d, d->dbgd);
+    if (rc) return fail(MJB_ERR_DEVICE, "device allocation of debug buffers failed");
+    d->dbg_ready = true;
+  }
+  ObsSpecDev none; std::memset(&none, 0, sizeof(none));
+  return launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, true);
+}
+
+int mjb_debug_get(mjbData* d, const char* name, void* host_out, long capacity_elems) {
+  if (!d || !name || !host_out) return fail(MJB_ERR_ARG, "NULL argument");
+  if (!d->dbg_ready) return fail(MJB_ERR_ARG, "call mjb_debug_forward first");
+  auto it = d->dbg_arrays.find(name);
+  if (it == d->dbg_arrays.end()) return fail(MJB_ERR_ARG, std::string("unknown debug array: ") + name);
+  const ArrayInfo& ai = it->second;
+  long n = (long)d->batch * ai.per_env;
+  if (capacity_elems < n) return fail(MJB_ERR_ARG, "output buffer too small");
+  HIPCHK(hipSetDevice(d->device));
+  if (ai.kind == 2) {
+    HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipMemcpy(host_out, ai.ptr, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return MJB_OK;
+  }
+  return copy_out(d, ai, (double*)host_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,1465 @@
+// mjb_device.hpp — the batched mj_step pipeline as group-cooperative device code.
+//
+// One *group* of G lanes (G = 64: one CDNA4 wavefront; smaller G packs several
+// environments into one wavefront for small models) advances one environment.
+// All per-environment intermediates live in that group's LDS slice (layout:
+// mjb::Lay); model constants are read through the vector cache (identical
+// addresses for every wave -> L1/L2 hits).  Control flow is group-uniform;
+// lanes split the work by index (bodies of one tree level, dofs, geom pairs,
+// constraint rows, matrix entries) and meet at gsync().
+//
+// Replaces, per environment, the third-party calls behind the reference's
+//   ModelHandle.step/forward  (reference mujoco_template/model.py:53-57)
+// following MuJoCo's documented pipeline [MJ-KNOWLEDGE].
+//
+// The same source compiles in a host emulation (MJB_HOST_EMU: one std::thread
+// per lane, real barriers) that only the CPU test-suite uses to check the
+// kernel logic without a GPU; the product library never contains that build.
+#pragma once
+#include "mjb_types.hpp"
+
+#ifdef MJB_HOST_EMU
+#include <cmath>
+#include "mjb_hostemu.hpp"
+#define MJB_DEV static inline
+#define MJB_DEVM inline
+#else
+#include <hip/hip_runtime.h>
+#define MJB_DEV __device__ __forceinline__
+#define MJB_DEVM __device__ __forceinline__
+#endif
+
+namespace mjb {
+
+// ---------------------------------------------------------------------------
+// group primitives
+// ---------------------------------------------------------------------------
+#ifndef MJB_HOST_EMU
+template <int G> MJB_DEV void gsync() { __syncthreads(); }   // block == one wavefront: lowers to a wave barrier
+template <typename T, int G> MJB_DEV T gsum(T v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+template <int G> MJB_DEV int gsumi(int v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+template <int G> MJB_DEV int gscan_excl(int v, int lane, int& total) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) { int y = __shfl_up(x, o, G); if (lane >= o) x += y; }
+  total = __shfl(x, G - 1, G);
+  return x - v;
+}
+template <typename T, int G> MJB_DEV T gshfl(T v, int src) { return __shfl(v, src, G); }
+template <int G> MJB_DEV int gmaxi(int v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) { int y = __shfl_xor(v, o, G); v = y > v ? y : v; }
+  return v;
+}
+#endif
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+  MJB_DEVM static float minval() { return 1e-15f; }
+};
+template <> struct Num<double> {
+  MJB_DEVM static double minval() { return 1e-15; }
+};
+#define MJB_MINIMP ((T)0.0001)
+#define MJB_MAXIMP ((T)0.9999)
+#define MJB_PI ((T)3.14159265358979323846)
+
+template <typename T> MJB_DEV T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> MJB_DEV T t_min(T a, T b) { return a < b ? a : b; }
+template <typename T> MJB_DEV T t_abs(T a) { return a < 0 ? -a : a; }
+MJB_DEV float t_sqrt(float a) { return sqrtf(a); }
+MJB_DEV double t_sqrt(double a) { return sqrt(a); }
+MJB_DEV float t_sin(float a) { return sinf(a); }
+MJB_DEV double t_sin(double a) { return sin(a); }
+MJB_DEV float t_cos(float a) { return cosf(a); }
+MJB_DEV double t_cos(double a) { return cos(a); }
+MJB_DEV float t_atan2(float a, float b) { return atan2f(a, b); }
+MJB_DEV double t_atan2(double a, double b) { return atan2(a, b); }
+MJB_DEV float t_pow(float a, float b) { return powf(a, b); }
+MJB_DEV double t_pow(double a, double b) { return pow(a, b); }
+
+// ---------------------------------------------------------------------------
+// 3-vector / quaternion / spatial helpers (register resident)
+// ---------------------------------------------------------------------------
+template <typename T> MJB_DEV T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename T> MJB_DEV void cross3(T* r, const T* a, const T* b) {
+  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> MJB_DEV T normalize3(T* a) {
+  T n = t_sqrt(dot3(a, a));
+  if (n < Num<T>::minval()) { a[0] = 1; a[1] = 0; a[2] = 0; } else { T s = 1 / n; a[0] *= s; a[1] *= s; a[2] *= s; }
+  return n;
+}
+template <typename T> MJB_DEV void mulmatvec3(T* r, const T* m, const T* v) {
+  T x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> MJB_DEV void mulmatTvec3(T* r, const T* m, const T* v) {
+  T x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2], z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> MJB_DEV void quat_mul(T* r, const T* a, const T* b) {
+  T w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  T x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  T y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  T z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+template <typename T> MJB_DEV void quat_normalize(T* q) {
+  T n = t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < Num<T>::minval()) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { T s = 1 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+}
+template <typename T> MJB_DEV void quat2mat(T* m, const T* q) {
+  T w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+template <typename T> MJB_DEV void axisangle2quat(T* q, const T* axis, T angle) {
+  T s = t_sin(angle * (T)0.5);
+  q[0] = t_cos(angle * (T)0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+template <typename T> MJB_DEV void quat_integrate(T* q, const T* w, T h) {
+  T ax[3] = {w[0], w[1], w[2]};
+  T n = normalize3(ax);
+  if (n < Num<T>::minval()) return;
+  T qr[4], out[4];
+  axisangle2quat(qr, ax, h * n);
+  quat_mul(out, q, qr);
+  quat_normalize(out);
+  q[0] = out[0]; q[1] = out[1]; q[2] = out[2]; q[3] = out[3];
+}
+template <typename T> MJB_DEV void quat_sub(T* res, const T* qa, const T* qb) {
+  T qn[4] = {qa[0], -qa[1], -qa[2], -qa[3]}, qd[4];
+  quat_mul(qd, qn, qb);
+  T ax[3] = {qd[1], qd[2], qd[3]};
+  T s = t_sqrt(dot3(ax, ax));
+  if (s < Num<T>::minval()) { res[0] = res[1] = res[2] = 0; return; }
+  T ang = 2 * t_atan2(s, qd[0]);
+  if (ang > MJB_PI) ang -= 2 * MJB_PI;
+  T k = ang / s;
+  res[0] = ax[0] * k; res[1] = ax[1] * k; res[2] = ax[2] * k;
+}
+template <typename T> MJB_DEV void inert_com(T* res, const T* inert, const T* mat, const T* dif, T mass) {
+  T tmp[9];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) tmp[3 * k + j] = inert[k] * mat[3 * j + k];
+  res[0] = mat[0] * tmp[0] + mat[1] * tmp[3] + mat[2] * tmp[6];
+  res[1] = mat[3] * tmp[1] + mat[4] * tmp[4] + mat[5] * tmp[7];
+  res[2] = mat[6] * tmp[2] + mat[7] * tmp[5] + mat[8] * tmp[8];
+  res[3] = mat[0] * tmp[1] + mat[1] * tmp[4] + mat[2] * tmp[7];
+  res[4] = mat[0] * tmp[2] + mat[1] * tmp[5] + mat[2] * tmp[8];
+  res[5] = mat[3] * tmp[2] + mat[4] * tmp[5] + mat[5] * tmp[8];
+  res[0] += mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+  res[1] += mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+  res[2] += mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+  res[3] -= mass * dif[0] * dif[1];
+  res[4] -= mass * dif[0] * dif[2];
+  res[5] -= mass * dif[1] * dif[2];
+  res[6] = mass * dif[0]; res[7] = mass * dif[1]; res[8] = mass * dif[2]; res[9] = mass;
+}
+template <typename T> MJB_DEV void mul_inert_vec(T* res, const T* i, const T* v) {
+  res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  res[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  res[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+template <typename T> MJB_DEV void cross_motion(T* res, const T* vel, const T* v) {
+  res[0] = -vel[2] * v[1] + vel[1] * v[2];
+  res[1] = vel[2] * v[0] - vel[0] * v[2];
+  res[2] = -vel[1] * v[0] + vel[0] * v[1];
+  res[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  res[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  res[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+template <typename T> MJB_DEV void cross_force(T* res, const T* vel, const T* f) {
+  res[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  res[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  res[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  res[3] = -vel[2] * f[4] + vel[1] * f[5];
+  res[4] = vel[2] * f[3] - vel[0] * f[5];
+  res[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+
+// triangle enumeration idx -> (r, c), 0 <= c <= r, idx = r(r+1)/2 + c (exact for idx < 2^22)
+MJB_DEV void tri_rc(int idx, int& r, int& c) {
+  int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+  while ((rr + 1) * (rr + 2) / 2 <= idx) rr++;
+  while (rr * (rr + 1) / 2 > idx) rr--;
+  r = rr; c = idx - rr * (rr + 1) / 2;
+}
+
+// ---------------------------------------------------------------------------
+// dense Cholesky in LDS (lower triangle, in place) + solve.  dinv receives 1/L[j][j].
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void chol_factor(T* A, T* dinv, int n, int lane) {
+  for (int j = 0; j < n; j++) {
+    gsync<G>();
+    T ajj = A[j * n + j];
+    T ljj = t_sqrt(t_max(ajj, Num<T>::minval()));
+    T inv = 1 / ljj;
+    gsync<G>();
+    for (int i = j + 1 + lane; i < n; i += G) A[i * n + j] *= inv;
+    if (lane == 0) { A[j * n + j] = ljj; dinv[j] = inv; }
+    gsync<G>();
+    int t = n - 1 - j, np = t * (t + 1) / 2;
+    for (int idx = lane; idx < np; idx += G) {
+      int r, c;
+      tri_rc(idx, r, c);
+      int i = j + 1 + r, k = j + 1 + c;
+      A[i * n + k] -= A[i * n + j] * A[k * n + j];
+    }
+  }
+  gsync<G>();
+}
+
+// x (LDS vector, length n) <- (L L^T)^-1 x.   Uses one lane per row when G >= n.
+template <typename T, int G> MJB_DEV void chol_solve(const T* L, const T* dinv, T* x, int n, int lane) {
+  gsync<G>();
+  if (G >= n) {
+    T r = lane < n ? x[lane] : (T)0;
+    for (int j = 0; j < n; j++) {                       // forward: L y = b
+      T xj = gshfl<T, G>(r, j) * dinv[j];
+      if (lane == j) r = xj;
+      else if (lane > j && lane < n) r -= L[lane * n + j] * xj;
+    }
+    for (int j = n - 1; j >= 0; j--) {                  // backward: L^T x = y
+      T xj = gshfl<T, G>(r, j) * dinv[j];
+      if (lane == j) r = xj;
+      else if (lane < j) r -= L[j * n + lane] * xj;
+    }
+    if (lane < n) x[lane] = r;
+  } else {
+    for (int j = 0; j < n; j++) {
+      T xj = x[j] * dinv[j];
+      gsync<G>();
+      if (lane == 0) x[j] = xj;
+      for (int i = j + 1 + lane; i < n; i += G) x[i] -= L[i * n + j] * xj;
+      gsync<G>();
+    }
+    for (int j = n - 1; j >= 0; j--) {
+      T xj = x[j] * dinv[j];
+      gsync<G>();
+      if (lane == 0) x[j] = xj;
+      for (int i = lane; i < j; i += G) x[i] -= L[j * n + i] * xj;
+      gsync<G>();
+    }
+  }
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// environment context: LDS slice + model, passed to every phase
+// ---------------------------------------------------------------------------
+template <typename T> struct Ctx {
+  const DevModel<T>& m;
+  const Lay& L;
+  T* w;      // T region of this environment's LDS slice
+  int* wi;   // int region
+  int lane;
+  int ncon, nefc, niter, con_dropped, efc_dropped;
+  MJB_DEVM Ctx(const DevModel<T>& m_, const Lay& L_, T* w_, int* wi_, int lane_) : m(m_), L(L_), w(w_), wi(wi_), lane(lane_), ncon(0), nefc(0), niter(0), con_dropped(0), efc_dropped(0) {}
+};
+
+// ---------------------------------------------------------------------------
+// A1 kinematics: tree levels in order, bodies of a level across lanes
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane;
+  T *xpos = w + L.xpos, *xquat = w + L.xquat, *xmat = w + L.xmat, *xipos = w + L.xipos, *ximat = w + L.ximat;
+  T *qpos = w + L.qpos, *xanchor = w + L.xanchor, *xaxis = w + L.xaxis;
+  if (lane == 0) {
+    xpos[0] = xpos[1] = xpos[2] = 0; xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
+    xipos[0] = xipos[1] = xipos[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { xmat[k] = (k % 4 == 0) ? (T)1 : (T)0; ximat[k] = xmat[k]; }
+  }
+  gsync<G>();
+  for (int lev = 0; lev < m.nlevel; lev++) {
+    int a0 = m.level_adr[lev], a1 = m.level_adr[lev + 1];
+    for (int idx = a0 + lane; idx < a1; idx += G) {
+      int b = m.level_body[idx], p = m.body_parentid[b], jadr = m.body_jntadr[b], jnum = m.body_jntnum[b];
+      T pos[3], quat[4], R[9];
+      if (jnum == 1 && m.jnt_type[jadr] == JNT_FREE) {
+        int qa = m.jnt_qposadr[jadr];
+        quat[0] = qpos[qa + 3]; quat[1] = qpos[qa + 4]; quat[2] = qpos[qa + 5]; quat[3] = qpos[qa + 6];
+        quat_normalize(quat);
+        qpos[qa + 3] = quat[0]; qpos[qa + 4] = quat[1]; qpos[qa + 5] = quat[2]; qpos[qa + 6] = quat[3];
+        pos[0] = qpos[qa]; pos[1] = qpos[qa + 1]; pos[2] = qpos[qa + 2];
+        xanchor[3 * jadr] = pos[0]; xanchor[3 * jadr + 1] = pos[1]; xanchor[3 * jadr + 2] = pos[2];
+        xaxis[3 * jadr] = 0; xaxis[3 * jadr + 1] = 0; xaxis[3 * jadr + 2] = 1;
+      } else {
+        T bp[3] = {m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]};
+        T bq[4] = {m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]};
+        T pm[9], pq[4];
+#pragma unroll
+        for (int k = 0; k < 9; k++) pm[k] = xmat[9 * p + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pq[k] = xquat[4 * p + k];
+        mulmatvec3(pos, pm, bp);
+        pos[0] += xpos[3 * p]; pos[1] += xpos[3 * p + 1]; pos[2] += xpos[3 * p + 2];
+        quat_mul(quat, pq, bq);
+        for (int j = jadr; j < jadr + jnum; j++) {
+          T jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
+          T ja[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
+          T anchor[3], axis[3];
+          quat2mat(R, quat);
+          mulmatvec3(anchor, R, jp);
+          anchor[0] += pos[0]; anchor[1] += pos[1]; anchor[2] += pos[2];
+          mulmatvec3(axis, R, ja);
+          xanchor[3 * j] = anchor[0]; xanchor[3 * j + 1] = anchor[1]; xanchor[3 * j + 2] = anchor[2];
+          xaxis[3 * j] = axis[0]; xaxis[3 * j + 1] = axis[1]; xaxis[3 * j + 2] = axis[2];
+          int qa = m.jnt_qposadr[j];
+          T val = qpos[qa] - m.qpos0[qa];
+          if (m.jnt_type[j] == JNT_SLIDE) {
+            pos[0] += axis[0] * val; pos[1] += axis[1] * val; pos[2] += axis[2] * val;
+          } else {
+            T ql[4], qn[4], v[3];
+            axisangle2quat(ql, ja, val);
+            quat_mul(qn, quat, ql);
+            quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+            quat2mat(R, quat);
+            mulmatvec3(v, R, jp);
+            pos[0] = anchor[0] - v[0]; pos[1] = anchor[1] - v[1]; pos[2] = anchor[2] - v[2];
+          }
+        }
+      }
+      quat_normalize(quat);
+      quat2mat(R, quat);
+      T ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]};
+      T iq[4] = {m.body_iquat[4 * b], m.body_iquat[4 * b + 1], m.body_iquat[4 * b + 2], m.body_iquat[4 * b + 3]};
+      T t[3], q2[4], R2[9];
+      mulmatvec3(t, R, ip);
+      quat_mul(q2, quat, iq);
+      quat2mat(R2, q2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { xpos[3 * b + k] = pos[k]; xipos[3 * b + k] = pos[k] + t[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) xquat[4 * b + k] = quat[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { xmat[9 * b + k] = R[k]; ximat[9 * b + k] = R2[k]; }
+    }
+    gsync<G>();
+  }
+  T *gx = w + L.geom_xpos, *gm = w + L.geom_xmat, *sx = w + L.site_xpos, *sm = w + L.site_xmat;
+  for (int g = lane; g < m.ngeom + m.nsite; g += G) {
+    bool is_geom = g < m.ngeom;
+    int id = is_geom ? g : g - m.ngeom;
+    int b = is_geom ? m.geom_bodyid[id] : m.site_bodyid[id];
+    const T* lp = is_geom ? m.geom_pos + 3 * id : m.site_pos + 3 * id;
+    const T* lq = is_geom ? m.geom_quat + 4 * id : m.site_quat + 4 * id;
+    T p3[3] = {lp[0], lp[1], lp[2]}, q4[4] = {lq[0], lq[1], lq[2], lq[3]}, bm[9], bq[4], t[3], q[4], R[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) bm[k] = xmat[9 * b + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) bq[k] = xquat[4 * b + k];
+    mulmatvec3(t, bm, p3);
+    quat_mul(q, bq, q4);
+    quat_normalize(q);
+    quat2mat(R, q);
+    T* op = is_geom ? gx + 3 * id : sx + 3 * id;
+    T* om = is_geom ? gm + 9 * id : sm + 9 * id;
+#pragma unroll
+    for (int k = 0; k < 3; k++) op[k] = xpos[3 * b + k] + t[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) om[k] = R[k];
+  }
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// A2 com-frame quantities: subtree_com, cinert, cdof
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane;
+  T *sc = w + L.subtree_com, *xipos = w + L.xipos, *ximat = w + L.ximat, *xmat = w + L.xmat;
+  for (int b = lane; b < m.nbody; b += G) {
+    T ms = m.body_mass[b];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sc[3 * b + k] = ms * xipos[3 * b + k];
+  }
+  gsync<G>();
+  for (int lev = m.nlevel - 1; lev >= -1; lev--) {      // lev == -1: the world body
+    int a0 = lev >= 0 ? m.level_adr[lev] : 0, a1 = lev >= 0 ? m.level_adr[lev + 1] : 1;
+    for (int idx = a0 + lane; idx < a1; idx += G) {
+      int b = lev >= 0 ? m.level_body[idx] : 0;
+      T s[3] = {sc[3 * b], sc[3 * b + 1], sc[3 * b + 2]};
+      for (int ci = m.child_adr[b]; ci < m.child_adr[b + 1]; ci++) {
+        int ch = m.child_id[ci];
+        s[0] += sc[3 * ch]; s[1] += sc[3 * ch + 1]; s[2] += sc[3 * ch + 2];
+      }
+      sc[3 * b] = s[0]; sc[3 * b + 1] = s[1]; sc[3 * b + 2] = s[2];
+    }
+    gsync<G>();
+  }
+  for (int b = lane; b < m.nbody; b += G) {
+    T sm = m.body_subtreemass[b];
+    if (sm < Num<T>::minval()) { sc[3 * b] = xipos[3 * b]; sc[3 * b + 1] = xipos[3 * b + 1]; sc[3 * b + 2] = xipos[3 * b + 2]; }
+    else { T inv = 1 / sm; sc[3 * b] *= inv; sc[3 * b + 1] *= inv; sc[3 * b + 2] *= inv; }
+  }
+  gsync<G>();
+  T* cin = w + L.cinert;
+  for (int b = lane; b < m.nbody; b += G) {
+    if (b == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) cin[k] = 0;
+      continue;
+    }
+    int r = m.body_rootid[b];
+    T off[3], im[9], res[10];
+    T inr[3] = {m.body_inertia[3 * b], m.body_inertia[3 * b + 1], m.body_inertia[3 * b + 2]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) off[k] = xipos[3 * b + k] - sc[3 * r + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) im[k] = ximat[9 * b + k];
+    inert_com(res, inr, im, off, m.body_mass[b]);
+#pragma unroll
+    for (int k = 0; k < 10; k++) cin[10 * b + k] = res[k];
+  }
+  T *cdof = w + L.cdof, *xanchor = w + L.xanchor, *xaxis = w + L.xaxis;
+  for (int j = lane; j < m.njnt; j += G) {
+    int b = m.jnt_bodyid[j], da = m.jnt_dofadr[j], r = m.body_rootid[b], jt = m.jnt_type[j];
+    T off[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) off[k] = sc[3 * r + k] - xanchor[3 * j + k];
+    T* cd = cdof + 6 * da;
+    if (jt == JNT_FREE) {
+      for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cd[6 * i + k] = (k == 3 + i) ? (T)1 : (T)0;
+        T ax[3] = {xmat[9 * b + i], xmat[9 * b + 3 + i], xmat[9 * b + 6 + i]}, cr[3];
+        cross3(cr, ax, off);
+        T* cc = cd + 6 * (3 + i);
+        cc[0] = ax[0]; cc[1] = ax[1]; cc[2] = ax[2]; cc[3] = cr[0]; cc[4] = cr[1]; cc[5] = cr[2];
+      }
+    } else if (jt == JNT_SLIDE) {
+      cd[0] = cd[1] = cd[2] = 0; cd[3] = xaxis[3 * j]; cd[4] = xaxis[3 * j + 1]; cd[5] = xaxis[3 * j + 2];
+    } else {
+      T ax[3] = {xaxis[3 * j], xaxis[3 * j + 1], xaxis[3 * j + 2]}, cr[3];
+      cross3(cr, ax, off);
+      cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2]; cd[3] = cr[0]; cd[4] = cr[1]; cd[5] = cr[2];
+    }
+  }
+  // fixed tendons: length and Jacobian
+  T *tl = w + L.ten_length, *tj = w + L.ten_J, *qpos = w + L.qpos;
+  for (int t = lane; t < m.ntendon; t += G) {
+    for (int i = 0; i < m.nv; i++) tj[t * m.nv + i] = 0;
+    T len = 0;
+    for (int wi = m.tendon_adr[t]; wi < m.tendon_adr[t] + m.tendon_num[t]; wi++) {
+      int j = m.wrap_objid[wi];
+      len += m.wrap_prm[wi] * qpos[m.jnt_qposadr[j]];
+      tj[t * m.nv + m.jnt_dofadr[j]] = m.wrap_prm[wi];
+    }
+    tl[t] = len;
+  }
+  gsync<G>();
+}
+
+// Jacobian column of dof i for a world point attached to body b (zero if i does not move b)
+template <typename T> MJB_DEV void jac_col(const Ctx<T>& c, int b, int i, const T* point, T* jp, T* jr) {
+  const DevModel<T>& m = c.m;
+  jp[0] = jp[1] = jp[2] = 0;
+  if (jr) { jr[0] = jr[1] = jr[2] = 0; }
+  if (!((m.body_dofmask[b] >> i) & 1ull)) return;
+  const T* cd = c.w + c.L.cdof + 6 * i;
+  const T* sc = c.w + c.L.subtree_com + 3 * m.body_rootid[b];
+  T off[3] = {point[0] - sc[0], point[1] - sc[1], point[2] - sc[2]}, ang[3] = {cd[0], cd[1], cd[2]}, t[3];
+  cross3(t, ang, off);
+  jp[0] = cd[3] + t[0]; jp[1] = cd[4] + t[1]; jp[2] = cd[5] + t[2];
+  if (jr) { jr[0] = ang[0]; jr[1] = ang[1]; jr[2] = ang[2]; }
+}
+
+// ---------------------------------------------------------------------------
+// A4 composite rigid body -> dense M in LDS, Cholesky factor in W
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  T *crb = w + L.crb, *cin = w + L.cinert, *cdof = w + L.cdof, *buf = w + L.dofbuf, *M = w + L.M, *W = w + L.W;
+  for (int i = lane; i < 10 * m.nbody; i += G) crb[i] = cin[i];
+  gsync<G>();
+  for (int lev = m.nlevel - 1; lev >= 0; lev--) {
+    for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
+      int b = m.level_body[idx];
+      if (m.child_adr[b] == m.child_adr[b + 1]) continue;
+      T s[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) s[k] = crb[10 * b + k];
+      for (int ci = m.child_adr[b]; ci < m.child_adr[b + 1]; ci++) {
+        int ch = m.child_id[ci];
+#pragma unroll
+        for (int k = 0; k < 10; k++) s[k] += crb[10 * ch + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 10; k++) crb[10 * b + k] = s[k];
+    }
+    gsync<G>();
+  }
+  for (int i = lane; i < nv; i += G) {
+    T in[10], v[6], r[6];
+    int b = m.dof_bodyid[i];
+#pragma unroll
+    for (int k = 0; k < 10; k++) in[k] = crb[10 * b + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = cdof[6 * i + k];
+    mul_inert_vec(r, in, v);
+#pragma unroll
+    for (int k = 0; k < 6; k++) buf[6 * i + k] = r[k];
+  }
+  gsync<G>();
+  int tot = nv << m.nvshift;
+  for (int idx = lane; idx < tot; idx += G) {
+    int i = idx >> m.nvshift, j = idx & (m.nvp - 1);
+    if (j > i || j >= nv) continue;
+    T val = 0;
+    if ((m.dof_ancmask[i] >> j) & 1ull) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) val += cdof[6 * j + k] * buf[6 * i + k];
+      if (i == j) val += m.dof_armature[i];
+    }
+    M[i * nv + j] = val; M[j * nv + i] = val;
+    W[i * nv + j] = val;
+  }
+  gsync<G>();
+  chol_factor<T, G>(W, w + L.tmp, nv, lane);
+}
+
+// ---------------------------------------------------------------------------
+// A5 collision: static pair list, narrow phase per lane, ordered compaction
+// ---------------------------------------------------------------------------
+template <typename T> struct RawCon { T dist, pos[3], n[3], yh[3]; };
+
+template <typename T> MJB_DEV int nc_sphere_sphere(const T* p1, T r1, const T* p2, T r2, T margin, RawCon<T>& o) {
+  T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  T cd = t_sqrt(dot3(dif, dif)), dist = cd - r1 - r2;
+  if (dist > margin) return 0;
+  if (cd < Num<T>::minval()) { o.n[0] = 1; o.n[1] = 0; o.n[2] = 0; } else { T s = 1 / cd; o.n[0] = dif[0] * s; o.n[1] = dif[1] * s; o.n[2] = dif[2] * s; }
+  o.dist = dist; o.yh[0] = o.yh[1] = o.yh[2] = 0;
+  T k = r1 + (T)0.5 * dist;
+  o.pos[0] = p1[0] + o.n[0] * k; o.pos[1] = p1[1] + o.n[1] * k; o.pos[2] = p1[2] + o.n[2] * k;
+  return 1;
+}
+template <typename T> MJB_DEV int nc_plane_sphere(const T* pp, const T* n, const T* sp, T r, T margin, RawCon<T>& o) {
+  T dif[3] = {sp[0] - pp[0], sp[1] - pp[1], sp[2] - pp[2]};
+  T dist = dot3(dif, n) - r;
+  if (dist > margin) return 0;
+  o.dist = dist; o.n[0] = n[0]; o.n[1] = n[1]; o.n[2] = n[2]; o.yh[0] = o.yh[1] = o.yh[2] = 0;
+  T k = -(r + (T)0.5 * dist);
+  o.pos[0] = sp[0] + n[0] * k; o.pos[1] = sp[1] + n[1] * k; o.pos[2] = sp[2] + n[2] * k;
+  return 1;
+}
+
+template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane;
+  T *gx = w + L.geom_xpos, *gm = w + L.geom_xmat, *con = w + L.con;
+  int* con_pair = c.wi + L.i_con_pair;
+  int ncon = 0, dropped = 0;
+  for (int base = 0; base < m.npair; base += G) {
+    int p = base + lane, n = 0;
+    RawCon<T> rc[4];
+    if (p < m.npair) {
+      int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p], t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      T margin = m.pair_margin[p];
+      T p1[3] = {gx[3 * g1], gx[3 * g1 + 1], gx[3 * g1 + 2]}, p2[3] = {gx[3 * g2], gx[3 * g2 + 1], gx[3 * g2 + 2]};
+      T s1[3] = {m.geom_size[3 * g1], m.geom_size[3 * g1 + 1], m.geom_size[3 * g1 + 2]};
+      T s2[3] = {m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]};
+      T z1[3] = {gm[9 * g1 + 2], gm[9 * g1 + 5], gm[9 * g1 + 8]}, z2[3] = {gm[9 * g2 + 2], gm[9 * g2 + 5], gm[9 * g2 + 8]};
+      if (t1 == G_PLANE) {
+        if (t2 == G_SPHERE) n = nc_plane_sphere(p1, z1, p2, s2[0], margin, rc[0]);
+        else if (t2 == G_CAPSULE) {
+#pragma unroll
+          for (int s = 0; s < 2; s++) {
+            T sg = s == 0 ? s2[1] : -s2[1];
+            T e[3] = {p2[0] + z2[0] * sg, p2[1] + z2[1] * sg, p2[2] + z2[2] * sg};
+            RawCon<T> tmp;
+            if (nc_plane_sphere(p1, z1, e, s2[0], margin, tmp)) {
+              tmp.yh[0] = z2[0]; tmp.yh[1] = z2[1]; tmp.yh[2] = z2[2];
+              if (n == 0) rc[0] = tmp; else rc[1] = tmp;
+              n++;
+            }
+          }
+        } else if (t2 == G_BOX) {
+          T bm[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) bm[k] = gm[9 * g2 + k];
+          T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+          T dist = dot3(dif, z1);
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            T v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3];
+            mulmatvec3(corner, bm, v);
+            T ld = dot3(z1, corner);
+            if (n < 4 && !(dist + ld > margin || ld > 0)) {
+              RawCon<T> tmp;
+              tmp.dist = dist + ld; tmp.n[0] = z1[0]; tmp.n[1] = z1[1]; tmp.n[2] = z1[2]; tmp.yh[0] = tmp.yh[1] = tmp.yh[2] = 0;
+              T k = -(T)0.5 * tmp.dist;
+#pragma unroll
+              for (int a = 0; a < 3; a++) tmp.pos[a] = corner[a] + p2[a] + z1[a] * k;
+              if (n == 0) rc[0] = tmp; else if (n == 1) rc[1] = tmp; else if (n == 2) rc[2] = tmp; else rc[3] = tmp;
+              n++;
+            }
+          }
+        } else if (t2 == G_ELLIPSOID) {
+          T em[9], nn[3] = {-z1[0], -z1[1], -z1[2]}, dl[3], s[3], wpt[3];
+#pragma unroll
+          for (int k = 0; k < 9; k++) em[k] = gm[9 * g2 + k];
+          mulmatTvec3(dl, em, nn);
+          T den = t_sqrt(s2[0] * s2[0] * dl[0] * dl[0] + s2[1] * s2[1] * dl[1] * dl[1] + s2[2] * s2[2] * dl[2] * dl[2]);
+          den = t_max(den, Num<T>::minval());
+#pragma unroll
+          for (int k = 0; k < 3; k++) s[k] = s2[k] * s2[k] * dl[k] / den;
+          mulmatvec3(wpt, em, s);
+          wpt[0] += p2[0]; wpt[1] += p2[1]; wpt[2] += p2[2];
+          T dif[3] = {wpt[0] - p1[0], wpt[1] - p1[1], wpt[2] - p1[2]};
+          T dist = dot3(dif, z1);
+          if (!(dist > margin)) {
+            rc[0].dist = dist; rc[0].n[0] = z1[0]; rc[0].n[1] = z1[1]; rc[0].n[2] = z1[2]; rc[0].yh[0] = rc[0].yh[1] = rc[0].yh[2] = 0;
+            T k = -(T)0.5 * dist;
+#pragma unroll
+            for (int a = 0; a < 3; a++) rc[0].pos[a] = wpt[a] + z1[a] * k;
+            n = 1;
+          }
+        }
+      } else if (t1 == G_SPHERE && t2 == G_SPHERE) {
+        n = nc_sphere_sphere(p1, s1[0], p2, s2[0], margin, rc[0]);
+      } else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
+        T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        T x = dot3(z2, dif);
+        x = t_min(t_max(x, -s2[1]), s2[1]);
+        T pt[3] = {p2[0] + z2[0] * x, p2[1] + z2[1] * x, p2[2] + z2[2] * x};
+        n = nc_sphere_sphere(p1, s1[0], pt, s2[0], margin, rc[0]);
+      } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {
+        T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        T ma = dot3(z1, z1), mb = -dot3(z1, z2), mc = dot3(z2, z2), u = -dot3(z1, dif), v = dot3(z2, dif);
+        T det = ma * mc - mb * mb, x1, x2;
+        if (t_abs(det) >= (T)1e-12) {
+          x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det;
+          if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; }
+          else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb * s1[1]) / mc; }
+          if (x2 > s2[1]) { x2 = s2[1]; x1 = t_min(t_max((u - mb * s2[1]) / ma, -s1[1]), s1[1]); }
+          else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = t_min(t_max((u + mb * s2[1]) / ma, -s1[1]), s1[1]); }
+        } else {
+          T lo = -s1[1], hi = s1[1], c2 = -dot3(z1, dif), sgn = mb < 0 ? (T)1 : (T)-1;
+          lo = t_max(lo, c2 - s2[1]); hi = t_min(hi, c2 + s2[1]);
+          x1 = lo <= hi ? (T)0.5 * (lo + hi) : (c2 > 0 ? s1[1] : -s1[1]);
+          x2 = t_min(t_max(sgn * (x1 - c2), -s2[1]), s2[1]);
+        }
+        T v1[3] = {p1[0] + z1[0] * x1, p1[1] + z1[1] * x1, p1[2] + z1[2] * x1};
+        T v2[3] = {p2[0] + z2[0] * x2, p2[1] + z2[1] * x2, p2[2] + z2[2] * x2};
+        n = nc_sphere_sphere(v1, s1[0], v2, s2[0], margin, rc[0]);
+      }
+    }
+    int total, off = gscan_excl<G>(n, lane, total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k < n) {
+        int slot = ncon + off + k;
+        if (slot < m.ncon_max) {
+          const RawCon<T>& r = rc[k];
+          T f[9] = {r.n[0], r.n[1], r.n[2], r.yh[0], r.yh[1], r.yh[2], 0, 0, 0};
+          normalize3(f);                                     // mju_makeFrame
+          if (dot3(f + 3, f + 3) < (T)0.25) {
+            f[3] = f[4] = f[5] = 0;
+            if (f[1] < (T)0.5 && f[1] > (T)-0.5) f[4] = 1; else f[5] = 1;
+          }
+          T d = dot3(f, f + 3);
+          f[3] -= d * f[0]; f[4] -= d * f[1]; f[5] -= d * f[2];
+          normalize3(f + 3);
+          cross3(f + 6, f, f + 3);
+          T* o = con + slot * CON_STRIDE;
+          o[0] = r.dist; o[1] = r.pos[0]; o[2] = r.pos[1]; o[3] = r.pos[2];
+#pragma unroll
+          for (int a = 0; a < 9; a++) o[4 + a] = f[a];
+          o[13] = m.pair_friction[5 * p];
+          con_pair[slot] = p;
+        }
+      }
+    }
+    int newn = ncon + total;
+    if (newn > m.ncon_max) { dropped += newn - (ncon > m.ncon_max ? ncon : m.ncon_max); }
+    ncon = newn;
+  }
+  c.con_dropped = dropped;
+  c.ncon = ncon < m.ncon_max ? ncon : m.ncon_max;
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// A6 constraint rows: limits + contacts; impedance, R/D, Jacobian, aref
+// ---------------------------------------------------------------------------
+template <typename T> MJB_DEV void row_params(const DevModel<T>& m, T pos, T margin, const T* solref, const T* solimp, T diagApprox, T& K, T& B, T& imp, T& R) {
+  T dmin = t_min(t_max(solimp[0], MJB_MINIMP), MJB_MAXIMP), dmax = t_min(t_max(solimp[1], MJB_MINIMP), MJB_MAXIMP);
+  T width = t_max(solimp[2], (T)0), mid = t_min(t_max(solimp[3], MJB_MINIMP), MJB_MAXIMP), power = t_max(solimp[4], (T)1);
+  if (dmin == dmax || width <= Num<T>::minval()) imp = (T)0.5 * (dmin + dmax);
+  else {
+    T x = t_abs(pos - margin) / width;
+    if (x >= 1) imp = dmax;
+    else if (x <= 0) imp = dmin;
+    else {
+      T y;
+      if (power == 1) y = x;
+      else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+      else if (x <= mid) y = t_pow(x, power) / t_pow(mid, power - 1);
+      else y = 1 - t_pow(1 - x, power) / t_pow(1 - mid, power - 1);
+      imp = dmin + y * (dmax - dmin);
+    }
+  }
+  if (solref[0] > 0) {
+    T tc = t_max(solref[0], 2 * m.timestep), dr = solref[1];
+    K = 1 / t_max(Num<T>::minval(), dmax * dmax * tc * tc * dr * dr);
+    B = 2 / t_max(Num<T>::minval(), dmax * tc);
+  } else {
+    K = -solref[0] / t_max(Num<T>::minval(), dmax * dmax);
+    B = -solref[1] / t_max(Num<T>::minval(), dmax);
+  }
+  R = t_max(Num<T>::minval(), (1 - imp) * diagApprox / imp);
+}
+
+template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, cap = m.nefc_max;
+  T *qpos = w + L.qpos, *qvel = w + L.qvel, *J = w + L.efc_J, *epos = w + L.efc_pos, *eD = w + L.efc_D, *earef = w + L.efc_aref;
+  T *eK = w + L.efc_jar, *eB = w + L.efc_jv, *eI = w + L.efc_force;       // K, B, imp scratch until aref is known
+  T *emargin = w + L.efc_KBI;
+  int *etype = c.wi + L.i_efc_type, *eid = c.wi + L.i_efc_id, *con_pair = c.wi + L.i_con_pair;
+  T *con = w + L.con, *tl = w + L.ten_length, *tj = w + L.ten_J;
+  int nefc = 0, dropped = 0;
+  // joint limits, then tendon limits: object `o`, side -1 (lower) then +1 (upper)
+  for (int pass = 0; pass < 2; pass++) {
+    int nobj = pass == 0 ? m.njnt : m.ntendon;
+    for (int base = 0; base < nobj; base += G) {
+      int o = base + lane, cnt = 0;
+      T dist[2] = {0, 0}, margin = 0;
+      bool act[2] = {false, false};
+      if (o < nobj) {
+        bool lim = pass == 0 ? (m.jnt_limited[o] && (m.jnt_type[o] == JNT_HINGE || m.jnt_type[o] == JNT_SLIDE)) : (m.tendon_limited[o] != 0);
+        if (lim) {
+          T value = pass == 0 ? qpos[m.jnt_qposadr[o]] : tl[o];
+          const T* rng = pass == 0 ? m.jnt_range + 2 * o : m.tendon_range + 2 * o;
+          margin = pass == 0 ? m.jnt_margin[o] : m.tendon_margin[o];
+          dist[0] = value - rng[0]; dist[1] = rng[1] - value;
+          act[0] = dist[0] < margin; act[1] = dist[1] < margin;
+          cnt = (int)act[0] + (int)act[1];
+        }
+      }
+      int total, off = gscan_excl<G>(cnt, lane, total);
+      int row = nefc + off;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        if (act[s]) {
+          if (row < cap) {
+            const T* solref = pass == 0 ? m.jnt_solref + 2 * o : m.tendon_solref + 2 * o;
+            const T* solimp = pass == 0 ? m.jnt_solimp + 5 * o : m.tendon_solimp + 5 * o;
+            T sr[2] = {solref[0], solref[1]}, si[5] = {solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
+            T diag = pass == 0 ? m.dof_invweight0[m.jnt_dofadr[o]] : m.tendon_invweight0[o];
+            T K, B, imp, R;
+            row_params(m, dist[s], margin, sr, si, diag, K, B, imp, R);
+            etype[row] = pass == 0 ? EFC_LIMIT_JOINT : EFC_LIMIT_TENDON;
+            eid[row] = o * 2 + s;
+            epos[row] = dist[s]; emargin[row] = margin; eD[row] = 1 / R; eK[row] = K; eB[row] = B; eI[row] = imp;
+          }
+          row++;
+        }
+      }
+      int newn = nefc + total;
+      if (newn > cap) dropped += newn - (nefc > cap ? nefc : cap);
+      nefc = newn;
+    }
+  }
+  if (nefc > cap) nefc = cap;
+  int* con_adr = c.wi + L.i_scal;    // first row of each contact (or -1)
+  int nlimit = nefc;
+  for (int base = 0; base < c.ncon; base += G) {
+    int ci = base + lane, rows = 0, p = 0;
+    T dist = 0, mu = 0, incm = 0;
+    if (ci < c.ncon) {
+      p = con_pair[ci];
+      dist = con[ci * CON_STRIDE]; mu = con[ci * CON_STRIDE + 13];
+      incm = m.pair_margin[p] - m.pair_gap[p];
+      if (dist < incm) rows = m.pair_condim[p] == 1 ? 1 : 4;
+    }
+    int total, off = gscan_excl<G>(rows, lane, total);
+    int row = nefc + off;
+    if (ci < c.ncon) {
+      bool fits = rows > 0 && row + rows <= cap;
+      con_adr[ci] = fits ? row : -1;
+      if (fits) {
+        int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
+        T tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+        T sr[2] = {m.pair_solref[2 * p], m.pair_solref[2 * p + 1]};
+        T si[5] = {m.pair_solimp[5 * p], m.pair_solimp[5 * p + 1], m.pair_solimp[5 * p + 2], m.pair_solimp[5 * p + 3], m.pair_solimp[5 * p + 4]};
+        T K, B, imp, R;
+        if (rows == 1) row_params(m, dist, incm, sr, si, tran, K, B, imp, R);
+        else {
+          row_params(m, dist, incm, sr, si, tran + mu * mu * tran, K, B, imp, R);
+          R = t_max(Num<T>::minval(), 2 * mu * mu * R);
+        }
+        for (int r = 0; r < rows; r++) {
+          etype[row + r] = rows == 1 ? EFC_CONTACT_FRICTIONLESS : EFC_CONTACT_PYRAMIDAL;
+          eid[row + r] = ci;
+          epos[row + r] = dist; emargin[row + r] = incm; eD[row + r] = 1 / R; eK[row + r] = K; eB[row + r] = B; eI[row + r] = imp;
+        }
+      }
+    }
+    int newn = nefc + total;
+    if (newn > cap) dropped += newn - (nefc > cap ? nefc : cap);
+    nefc = newn;
+  }
+  // contacts that did not fit leave holes only at the tail: rows are contiguous because offsets are monotone
+  if (nefc > cap) {
+    // recompute the true count = last fitting contact's end
+    int last = nlimit;
+    for (int ci = lane; ci < c.ncon; ci += G) {
+      int a = con_adr[ci];
+      if (a >= 0) { int p = con_pair[ci]; int e = a + (m.pair_condim[p] == 1 ? 1 : 4); if (e > last) last = e; }
+    }
+    nefc = gmaxi<G>(last);
+  }
+  c.nefc = nefc; c.efc_dropped = dropped;
+  gsync<G>();
+  // Jacobian rows of limits
+  {
+    int tot = nlimit << m.nvshift;
+    for (int idx = lane; idx < tot; idx += G) {
+      int r = idx >> m.nvshift, i = idx & (m.nvp - 1);
+      if (i >= nv) continue;
+      int o = eid[r] >> 1, s = eid[r] & 1;
+      T sign = s == 0 ? (T)1 : (T)-1, v;
+      if (etype[r] == EFC_LIMIT_JOINT) v = (i == m.jnt_dofadr[o]) ? sign : (T)0;
+      else v = sign * tj[o * nv + i];
+      J[r * nv + i] = v;
+    }
+  }
+  // Jacobian rows of contacts: (contact, dof) across lanes
+  {
+    int tot = c.ncon << m.nvshift;
+    for (int idx = lane; idx < tot; idx += G) {
+      int ci = idx >> m.nvshift, i = idx & (m.nvp - 1);
+      if (i >= nv) continue;
+      int row = con_adr[ci];
+      if (row < 0) continue;
+      int p = con_pair[ci];
+      int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
+      const T* cc = con + ci * CON_STRIDE;
+      T pos[3] = {cc[1], cc[2], cc[3]}, j1[3], j2[3], dj[3];
+      jac_col<T>(c, b1, i, pos, j1, (T*)0);
+      jac_col<T>(c, b2, i, pos, j2, (T*)0);
+      dj[0] = j2[0] - j1[0]; dj[1] = j2[1] - j1[1]; dj[2] = j2[2] - j1[2];
+      T jn = cc[4] * dj[0] + cc[5] * dj[1] + cc[6] * dj[2];
+      if (m.pair_condim[p] == 1) J[row * nv + i] = jn;
+      else {
+        T mu = cc[13];
+        T jt1 = mu * (cc[7] * dj[0] + cc[8] * dj[1] + cc[9] * dj[2]), jt2 = mu * (cc[10] * dj[0] + cc[11] * dj[1] + cc[12] * dj[2]);
+        J[row * nv + i] = jn + jt1; J[(row + 1) * nv + i] = jn - jt1;
+        J[(row + 2) * nv + i] = jn + jt2; J[(row + 3) * nv + i] = jn - jt2;
+      }
+    }
+  }
+  gsync<G>();
+  // reference acceleration: aref = -B (J qvel) - K imp (pos - margin)
+  for (int r = lane; r < nefc; r += G) {
+    T v = 0;
+    for (int i = 0; i < nv; i++) v += J[r * nv + i] * qvel[i];
+    earef[r] = -eB[r] * v - eK[r] * eI[r] * (epos[r] - emargin[r]);
+  }
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// A7 velocity stage: cvel, cdof_dot, bias forces (RNE), passive forces
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  T *cvel = w + L.cvel, *cacc = w + L.cacc, *cfrc = w + L.cfrc, *cdof = w + L.cdof, *cdd = w + L.cdof_dot, *cin = w + L.cinert;
+  T *qvel = w + L.qvel, *qpos = w + L.qpos;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cvel[k] = 0; cfrc[k] = 0; }
+    cacc[0] = cacc[1] = cacc[2] = 0; cacc[3] = -m.gravity[0]; cacc[4] = -m.gravity[1]; cacc[5] = -m.gravity[2];
+  }
+  gsync<G>();
+  for (int lev = 0; lev < m.nlevel; lev++) {
+    for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
+      int b = m.level_body[idx], p = m.body_parentid[b], da = m.body_dofadr[b], dn = m.body_dofnum[b];
+      T cv[6], ca[6], tmp[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { cv[k] = cvel[6 * p + k]; ca[k] = cacc[6 * p + k]; }
+      for (int j = da; j < da + dn;) {
+        int jt = m.jnt_type[m.dof_jntid[j]];
+        if (jt == JNT_FREE) {
+          for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) { cdd[6 * (j + k) + q] = 0; cv[q] += cdof[6 * (j + k) + q] * qvel[j + k]; }
+          }
+          j += 3;
+          for (int k = 0; k < 3; k++) {
+            T cd[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) cd[q] = cdof[6 * (j + k) + q];
+            cross_motion(tmp, cv, cd);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { cdd[6 * (j + k) + q] = tmp[q]; ca[q] += tmp[q] * qvel[j + k]; }
+          }
+          for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) cv[q] += cdof[6 * (j + k) + q] * qvel[j + k];
+          }
+          j += 3;
+        } else {
+          T cd[6];
+#pragma unroll
+          for (int q = 0; q < 6; q++) cd[q] = cdof[6 * j + q];
+          cross_motion(tmp, cv, cd);
+          T qv = qvel[j];
+#pragma unroll
+          for (int q = 0; q < 6; q++) { cdd[6 * j + q] = tmp[q]; ca[q] += tmp[q] * qv; cv[q] += cd[q] * qv; }
+          j++;
+        }
+      }
+      T in[10], f[6], t1[6], t2[6];
+#pragma unroll
+      for (int k = 0; k < 10; k++) in[k] = cin[10 * b + k];
+      mul_inert_vec(f, in, ca);
+      mul_inert_vec(t1, in, cv);
+      cross_force(t2, cv, t1);
+#pragma unroll
+      for (int k = 0; k < 6; k++) { cvel[6 * b + k] = cv[k]; cacc[6 * b + k] = ca[k]; cfrc[6 * b + k] = f[k] + t2[k]; }
+    }
+    gsync<G>();
+  }
+  for (int lev = m.nlevel - 1; lev >= 0; lev--) {
+    for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
+      int b = m.level_body[idx];
+      if (m.child_adr[b] == m.child_adr[b + 1]) continue;
+      T s[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) s[k] = cfrc[6 * b + k];
+      for (int ci = m.child_adr[b]; ci < m.child_adr[b + 1]; ci++) {
+        int ch = m.child_id[ci];
+#pragma unroll
+        for (int k = 0; k < 6; k++) s[k] += cfrc[6 * ch + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) cfrc[6 * b + k] = s[k];
+    }
+    gsync<G>();
+  }
+  // fluid forces per body (inertia-box model) into bfrc = [torque; force] at xipos
+  T* bfrc = w + L.bfrc;
+  if (m.has_fluid) {
+    T *xipos = w + L.xipos, *ximat = w + L.ximat, *sc = w + L.subtree_com;
+    for (int b = lane; b < m.nbody; b += G) {
+      T mass = m.body_mass[b];
+#pragma unroll
+      for (int k = 0; k < 6; k++) bfrc[6 * b + k] = 0;
+      if (b == 0 || mass < Num<T>::minval()) continue;
+      T I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2];
+      T box[3] = {t_sqrt(t_max(Num<T>::minval(), I1 + I2 - I0) / mass * 6), t_sqrt(t_max(Num<T>::minval(), I0 + I2 - I1) / mass * 6), t_sqrt(t_max(Num<T>::minval(), I0 + I1 - I2) / mass * 6)};
+      int r = m.body_rootid[b];
+      T cv[6], off[3], lin[3], t[3], im[9], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 6; k++) cv[k] = cvel[6 * b + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) off[k] = xipos[3 * b + k] - sc[3 * r + k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) im[k] = ximat[9 * b + k];
+      cross3(t, cv, off);
+      lin[0] = cv[3] + t[0]; lin[1] = cv[4] + t[1]; lin[2] = cv[5] + t[2];
+      mulmatTvec3(lvel, im, cv);
+      mulmatTvec3(lvel + 3, im, lin);
+      if (m.viscosity > 0) {
+        T diam = (box[0] + box[1] + box[2]) / 3;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lfrc[k] = -MJB_PI * diam * diam * diam * m.viscosity * lvel[k]; lfrc[3 + k] = -3 * MJB_PI * diam * m.viscosity * lvel[3 + k]; }
+      }
+      if (m.density > 0) {
+        lfrc[3] -= (T)0.5 * m.density * box[1] * box[2] * t_abs(lvel[3]) * lvel[3];
+        lfrc[4] -= (T)0.5 * m.density * box[0] * box[2] * t_abs(lvel[4]) * lvel[4];
+        lfrc[5] -= (T)0.5 * m.density * box[0] * box[1] * t_abs(lvel[5]) * lvel[5];
+        T b0 = box[0] * box[0], b1 = box[1] * box[1], b2 = box[2] * box[2];
+        lfrc[0] -= m.density * box[0] * (b1 * b1 + b2 * b2) * t_abs(lvel[0]) * lvel[0] / 64;
+        lfrc[1] -= m.density * box[1] * (b0 * b0 + b2 * b2) * t_abs(lvel[1]) * lvel[1] / 64;
+        lfrc[2] -= m.density * box[2] * (b0 * b0 + b1 * b1) * t_abs(lvel[2]) * lvel[2] / 64;
+      }
+      T o1[3], o2[3];
+      mulmatvec3(o1, im, lfrc);
+      mulmatvec3(o2, im, lfrc + 3);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { bfrc[6 * b + k] = o1[k]; bfrc[6 * b + 3 + k] = o2[k]; }
+    }
+    gsync<G>();
+  }
+  T *qb = w + L.qfrc_bias, *qp = w + L.qfrc_passive;
+  for (int i = lane; i < nv; i += G) {
+    int b = m.dof_bodyid[i], j = m.dof_jntid[i], jt = m.jnt_type[j];
+    T v = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v += cdof[6 * i + k] * cfrc[6 * b + k];
+    qb[i] = v;
+    T pf = -m.dof_damping[i] * qvel[i];
+    if ((jt == JNT_HINGE || jt == JNT_SLIDE) && m.jnt_stiffness[j] != 0) {
+      int qa = m.jnt_qposadr[j];
+      pf -= m.jnt_stiffness[j] * (qpos[qa] - m.qpos_spring[qa]);
+    }
+    if (m.has_fluid) {
+      T* xipos = w + L.xipos;
+      for (int bb = 1; bb < m.nbody; bb++) {
+        if (!((m.body_dofmask[bb] >> i) & 1ull)) continue;
+        T pt[3] = {xipos[3 * bb], xipos[3 * bb + 1], xipos[3 * bb + 2]}, jp[3], jr[3];
+        jac_col<T>(c, bb, i, pt, jp, jr);
+        pf += jp[0] * bfrc[6 * bb + 3] + jp[1] * bfrc[6 * bb + 4] + jp[2] * bfrc[6 * bb + 5] + jr[0] * bfrc[6 * bb] + jr[1] * bfrc[6 * bb + 1] + jr[2] * bfrc[6 * bb + 2];
+      }
+    }
+    qp[i] = pf;
+  }
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// A8/A9 actuation and unconstrained acceleration
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  T *ctrl = w + L.ctrl, *af = w + L.act_force, *qpos = w + L.qpos, *qvel = w + L.qvel;
+  for (int a = lane; a < m.nu; a += G) {
+    int grp = m.actuator_group[a];
+    T force = 0;
+    if (!(grp >= 0 && grp < 31 && ((m.disableactuator >> grp) & 1))) {
+      T u = ctrl[a];
+      if (m.actuator_ctrllimited[a]) u = t_min(t_max(u, m.actuator_ctrlrange[2 * a]), m.actuator_ctrlrange[2 * a + 1]);
+      force = m.actuator_gainprm[3 * a] * u;
+      if (m.actuator_biastype[a] == 1) {
+        T len = 0, vel = 0;
+        if (m.actuator_trntype[a] == TRN_JOINT) {
+          int j = m.actuator_trnid[2 * a];
+          len = m.actuator_gear[6 * a] * qpos[m.jnt_qposadr[j]];
+          vel = m.actuator_gear[6 * a] * qvel[m.jnt_dofadr[j]];
+        }
+        force += m.actuator_biasprm[3 * a] + m.actuator_biasprm[3 * a + 1] * len + m.actuator_biasprm[3 * a + 2] * vel;
+      }
+      if (m.actuator_forcelimited[a]) force = t_min(t_max(force, m.actuator_forcerange[2 * a]), m.actuator_forcerange[2 * a + 1]);
+    }
+    af[a] = force;
+  }
+  gsync<G>();
+  T *qa = w + L.qfrc_actuator, *qs = w + L.qfrc_smooth, *qas = w + L.qacc_smooth, *qb = w + L.qfrc_bias, *qp = w + L.qfrc_passive;
+  T *sx = w + L.site_xpos, *sm = w + L.site_xmat;
+  for (int i = lane; i < nv; i += G) {
+    T s = 0;
+    for (int a = 0; a < m.nu; a++) {
+      int id = m.actuator_trnid[2 * a];
+      if (m.actuator_trntype[a] == TRN_JOINT) {
+        if (m.jnt_dofadr[id] == i) s += m.actuator_gear[6 * a] * af[a];
+      } else {
+        int b = m.site_bodyid[id];
+        if (!((m.body_dofmask[b] >> i) & 1ull)) continue;
+        T g[6], R[9], f[3], tq[3], pt[3] = {sx[3 * id], sx[3 * id + 1], sx[3 * id + 2]}, jp[3], jr[3];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] = m.actuator_gear[6 * a + k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = sm[9 * id + k];
+        mulmatvec3(f, R, g);
+        mulmatvec3(tq, R, g + 3);
+        jac_col<T>(c, b, i, pt, jp, jr);
+        s += (dot3(jp, f) + dot3(jr, tq)) * af[a];
+      }
+    }
+    qa[i] = s;
+    T fs = qp[i] - qb[i] + s;
+    qs[i] = fs; qas[i] = fs;
+  }
+  gsync<G>();
+  chol_solve<T, G>(w + L.W, w + L.tmp, qas, nv, lane);
+}
+
+// ---------------------------------------------------------------------------
+// A10 Newton solver on the primal problem (limit / frictionless / pyramidal rows)
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, bool store) {
+  // Ma = M qacc, jar = J qacc - aref; returns Gauss + constraint cost.  store=false leaves force untouched.
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *aref = w + L.efc_aref, *D = w + L.efc_D, *force = w + L.efc_force;
+  T *qs = w + L.qfrc_smooth, *qas = w + L.qacc_smooth;
+  T part = 0;
+  for (int i = lane; i < nv; i += G) {
+    T s = 0;
+    for (int k = 0; k < nv; k++) s += M[i * nv + k] * qacc[k];
+    Ma[i] = s;
+    part += (T)0.5 * (s - qs[i]) * (qacc[i] - qas[i]);
+  }
+  for (int r = lane; r < nefc; r += G) {
+    T s = -aref[r];
+    for (int k = 0; k < nv; k++) s += J[r * nv + k] * qacc[k];
+    jar[r] = s;
+    if (s < 0) { part += (T)0.5 * D[r] * s * s; if (store) force[r] = -D[r] * s; }
+    else if (store) force[r] = 0;
+  }
+  T cost = gsum<T, G>(part);
+  gsync<G>();
+  return cost;
+}
+
+template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c) {
+  // grad, H = M + J^T D_active J (lower, into W), search = -H^-1 grad.  Returns |grad|^2.
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *D = w + L.efc_D, *force = w + L.efc_force;
+  T *grad = w + L.grad, *search = w + L.search, *qs = w + L.qfrc_smooth, *dw = w + L.efc_jv;
+  for (int r = lane; r < nefc; r += G) dw[r] = jar[r] < 0 ? D[r] : (T)0;
+  T gpart = 0;
+  for (int i = lane; i < nv; i += G) {
+    T g = Ma[i] - qs[i];
+    for (int r = 0; r < nefc; r++) g -= J[r * nv + i] * force[r];
+    grad[i] = g; search[i] = g;
+    gpart += g * g;
+  }
+  T gn = gsum<T, G>(gpart);
+  gsync<G>();
+  int np = nv * (nv + 1) / 2;
+  for (int idx = lane; idx < np; idx += G) {
+    int i, k;
+    tri_rc(idx, i, k);
+    T h = M[i * nv + k];
+    for (int r = 0; r < nefc; r++) {
+      T d = dw[r];
+      if (d != 0) h += d * J[r * nv + i] * J[r * nv + k];
+    }
+    W[i * nv + k] = h;
+  }
+  gsync<G>();
+  chol_factor<T, G>(W, w + L.tmp, nv, lane);
+  chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
+  for (int i = lane; i < nv; i += G) search[i] = -search[i];
+  gsync<G>();
+  return gn;
+}
+
+template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  T *qacc = w + L.qacc, *ws = w + L.qacc_ws, *qas = w + L.qacc_smooth, *qc = w + L.qfrc_constraint;
+  c.niter = 0;
+  if (nefc == 0) {
+    for (int i = lane; i < nv; i += G) { T a = qas[i]; qacc[i] = a; ws[i] = a; qc[i] = 0; }
+    gsync<G>();
+    return;
+  }
+  T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *jv = w + L.efc_jv, *D = w + L.efc_D, *force = w + L.efc_force;
+  T *search = w + L.search, *Mv = w + L.Mv, *qs = w + L.qfrc_smooth;
+  T cost_ws = solver_cost<T, G>(c, ws, false);
+  T cost_sm = solver_cost<T, G>(c, qas, false);
+  bool use_ws = cost_ws < cost_sm;
+  for (int i = lane; i < nv; i += G) qacc[i] = use_ws ? ws[i] : qas[i];
+  gsync<G>();
+  T cost = solver_cost<T, G>(c, qacc, true);
+  const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
+  T gn = newton_direction<T, G>(c);
+  for (int iter = 0; iter < m.iterations; iter++) {
+    if (scale * t_sqrt(gn) < m.tolerance) break;
+    // Mv, jv and the Gauss part of the 1-D quadratic
+    T p1 = 0, p2 = 0;
+    for (int i = lane; i < nv; i += G) {
+      T s = 0;
+      for (int k = 0; k < nv; k++) s += M[i * nv + k] * search[k];
+      Mv[i] = s;
+      p1 += search[i] * (Ma[i] - qs[i]); p2 += search[i] * s;
+    }
+    for (int r = lane; r < nefc; r += G) {
+      T s = 0;
+      for (int k = 0; k < nv; k++) s += J[r * nv + k] * search[k];
+      jv[r] = s;
+    }
+    T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
+    gsync<G>();
+    // exact line search on the convex piecewise-quadratic: safeguarded Newton on the derivative
+    T alpha = 0, lo = 0, hi = -1;
+    for (int it = 0; it < 50; it++) {
+      T d1p = 0, d2p = 0;
+      for (int r = lane; r < nefc; r += G) {
+        T x = jar[r] + alpha * jv[r];
+        if (x < 0) { T dj = D[r] * jv[r]; d1p += dj * x; d2p += dj * jv[r]; }
+      }
+      T d1 = g1 + alpha * g2 + gsum<T, G>(d1p), d2 = g2 + gsum<T, G>(d2p);
+      if (it == 0 && d1 >= 0) { alpha = 0; break; }
+      if (d2 < Num<T>::minval()) break;
+      if (t_abs(d1) < (sizeof(T) == 4 ? (T)1e-6 : (T)1e-14) * (t_abs(g1) + Num<T>::minval())) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      T an = alpha - d1 / d2;
+      if (an <= lo || (hi >= 0 && an >= hi)) an = hi >= 0 ? (T)0.5 * (lo + hi) : 2 * alpha + (T)1e-3;
+      if (an == alpha) break;
+      alpha = an;
+    }
+    if (alpha == 0) break;
+    T part = 0;
+    for (int i = lane; i < nv; i += G) {
+      T a = qacc[i] + alpha * search[i], ma = Ma[i] + alpha * Mv[i];
+      qacc[i] = a; Ma[i] = ma;
+      part += (T)0.5 * (ma - qs[i]) * (a - qas[i]);
+    }
+    for (int r = lane; r < nefc; r += G) {
+      T s = jar[r] + alpha * jv[r];
+      jar[r] = s;
+      if (s < 0) { part += (T)0.5 * D[r] * s * s; force[r] = -D[r] * s; } else force[r] = 0;
+    }
+    T old = cost;
+    cost = gsum<T, G>(part);
+    gsync<G>();
+    c.niter = iter + 1;
+    gn = newton_direction<T, G>(c);
+    if (scale * (old - cost) < m.tolerance) break;
+  }
+  for (int i = lane; i < nv; i += G) {
+    T s = 0;
+    for (int r = 0; r < nefc; r++) s += J[r * nv + i] * force[r];
+    qc[i] = s; ws[i] = qacc[i];
+  }
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// mj_forward for one environment (state in LDS)
+// ---------------------------------------------------------------------------
+template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
+  kinematics<T, G>(c);
+  com_pos<T, G>(c);
+  crb_factor<T, G>(c);
+  collision<T, G>(c);
+  make_constraint<T, G>(c);
+  vel_bias_passive<T, G>(c);
+  actuation_acceleration<T, G>(c);
+  solve_constraints<T, G>(c);
+}
+
+// A16 position integration for the joints of one environment (lanes over joints)
+template <typename T, int G> MJB_DEV void integrate_pos(const DevModel<T>& m, T* qpos, const T* qvel, T h, int lane) {
+  for (int j = lane; j < m.njnt; j += G) {
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    if (m.jnt_type[j] == JNT_FREE) {
+      qpos[qa] += h * qvel[da]; qpos[qa + 1] += h * qvel[da + 1]; qpos[qa + 2] += h * qvel[da + 2];
+      T q[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]}, wv[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]};
+      quat_integrate(q, wv, h);
+      qpos[qa + 3] = q[0]; qpos[qa + 4] = q[1]; qpos[qa + 5] = q[2]; qpos[qa + 6] = q[3];
+    } else qpos[qa] += h * qvel[da];
+  }
+}
+
+// A11 Euler with implicit joint damping (mj_Euler)
+template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  T *qacc = w + L.qacc, *qvel = w + L.qvel, *qpos = w + L.qpos, *tmpv = w + L.Mv, *M = w + L.M, *W = w + L.W;
+  T h = m.timestep;
+  if (m.has_damping) {
+    T *qs = w + L.qfrc_smooth, *qc = w + L.qfrc_constraint;
+    for (int i = lane; i < nv; i += G) tmpv[i] = qs[i] + qc[i];
+    int np = nv * (nv + 1) / 2;
+    for (int idx = lane; idx < np; idx += G) {
+      int i, k;
+      tri_rc(idx, i, k);
+      W[i * nv + k] = M[i * nv + k] + (i == k ? h * m.dof_damping[i] : (T)0);
+    }
+    gsync<G>();
+    chol_factor<T, G>(W, w + L.tmp, nv, lane);
+    chol_solve<T, G>(W, w + L.tmp, tmpv, nv, lane);
+  } else {
+    for (int i = lane; i < nv; i += G) tmpv[i] = qacc[i];
+    gsync<G>();
+  }
+  for (int i = lane; i < nv; i += G) qvel[i] += h * tmpv[i];
+  gsync<G>();
+  integrate_pos<T, G>(m, qpos, qvel, h, lane);
+  gsync<G>();
+}
+
+// A11 RK4 (mj_RungeKutta, N = 4).  rk scratch: X0q[nq] X0v[nv] Fv[4nv] Fa[4nv] dv[nv] da[nv]
+template <typename T, int G> MJB_DEV void rk4(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nq = m.nq;
+  T *qacc = w + L.qacc, *qvel = w + L.qvel, *qpos = w + L.qpos;
+  T *X0q = w + L.rk, *X0v = X0q + nq, *Fv = X0v + nv, *Fa = Fv + 4 * nv, *dv = Fa + 4 * nv, *da = dv + nv;
+  const T h = m.timestep;
+  const T A[9] = {(T)0.5, 0, 0, 0, (T)0.5, 0, 0, 0, 1}, Bc[4] = {(T)(1.0 / 6), (T)(1.0 / 3), (T)(1.0 / 3), (T)(1.0 / 6)};
+  for (int i = lane; i < nq; i += G) X0q[i] = qpos[i];
+  for (int i = lane; i < nv; i += G) { X0v[i] = qvel[i]; Fv[i] = qvel[i]; Fa[i] = qacc[i]; }
+  gsync<G>();
+  for (int st = 1; st < 4; st++) {
+    for (int i = lane; i < nv; i += G) {
+      T sv = 0, sa = 0;
+      for (int j = 0; j < 3; j++) { T a = A[(st - 1) * 3 + j]; if (a != 0) { sv += a * Fv[j * nv + i]; sa += a * Fa[j * nv + i]; } }
+      dv[i] = sv; qvel[i] = X0v[i] + h * sa;
+    }
+    for (int i = lane; i < nq; i += G) qpos[i] = X0q[i];
+    gsync<G>();
+    integrate_pos<T, G>(m, qpos, dv, h, lane);
+    gsync<G>();
+    forward<T, G>(c);
+    for (int i = lane; i < nv; i += G) { Fv[st * nv + i] = qvel[i]; Fa[st * nv + i] = qacc[i]; }
+    gsync<G>();
+  }
+  for (int i = lane; i < nv; i += G) {
+    T sv = 0, sa = 0;
+    for (int j = 0; j < 4; j++) { sv += Bc[j] * Fv[j * nv + i]; sa += Bc[j] * Fa[j * nv + i]; }
+    dv[i] = sv; qvel[i] = X0v[i] + h * sa;
+  }
+  for (int i = lane; i < nq; i += G) qpos[i] = X0q[i];
+  gsync<G>();
+  integrate_pos<T, G>(m, qpos, dv, h, lane);
+  gsync<G>();
+}
+
+// ---------------------------------------------------------------------------
+// counter-based uniform random ctrl (Philox4x32-10): identical to oracle/mjo.c
+// ---------------------------------------------------------------------------
+MJB_DEV unsigned philox_first(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+  for (int r = 0; r < 10; r++) {
+    unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+template <typename T, int G> MJB_DEV void random_ctrl(const DevModel<T>& m, T* ctrl, unsigned seed, unsigned env, unsigned step, T scale, int lane) {
+  for (int a = lane; a < m.nu; a += G) {
+    unsigned r = philox_first(env, step, (unsigned)a, 0u, seed, 0x5EEDu);
+    T u = (T)(r >> 8) * (T)(1.0 / 16777216.0);
+    T lo = -1, hi = 1;
+    if (m.actuator_ctrllimited[a]) { lo = m.actuator_ctrlrange[2 * a]; hi = m.actuator_ctrlrange[2 * a + 1]; }
+    ctrl[a] = (T)0.5 * (lo + hi) + (T)0.5 * (hi - lo) * scale * (2 * u - 1);
+  }
+}
+
+// A13 bad-state guard
+template <typename T, int G> MJB_DEV bool group_bad(const T* x, int n, int lane) {
+  int bad = 0;
+  for (int i = lane; i < n; i += G) { T v = x[i]; if (!(t_abs(v) <= (T)1e10)) bad = 1; }
+  return gsumi<G>(bad) != 0;
+}
+template <typename T, int G> MJB_DEV void reset_state(Ctx<T>& c) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w;
+  for (int i = c.lane; i < m.nq; i += G) w[L.qpos + i] = m.qpos0[i];
+  for (int i = c.lane; i < m.nv; i += G) { w[L.qvel + i] = 0; w[L.qacc + i] = 0; w[L.qacc_ws + i] = 0; }
+  for (int i = c.lane; i < m.nu; i += G) w[L.ctrl + i] = 0;
+  gsync<G>();
+}
+
+// flat observation (keys in sorted order, reference observations.py:171-174):
+// bodies_pos, ctrl, geoms_pos, qpos, qvel, sensordata, sites_pos, subtree_com, time
+template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c, const ObsSpecDev& s, double time, TS* out) {
+  const DevModel<T>& m = c.m; const Lay& L = c.L; const T* w = c.w; const int lane = c.lane;
+  int o = 0;
+  const T* bsrc = (s.flags & 64) ? w + L.xipos : w + L.xpos;
+  for (int i = lane; i < 3 * s.nbody; i += G) out[o + i] = (TS)bsrc[3 * s.body_ids[i / 3] + i % 3];
+  o += 3 * s.nbody;
+  if (s.flags & 4) { for (int i = lane; i < m.nu; i += G) out[o + i] = (TS)w[L.ctrl + i]; o += m.nu; }
+  for (int i = lane; i < 3 * s.ngeom; i += G) out[o + i] = (TS)w[L.geom_xpos + 3 * s.geom_ids[i / 3] + i % 3];
+  o += 3 * s.ngeom;
+  if (s.flags & 1) { for (int i = lane; i < m.nq; i += G) out[o + i] = (TS)w[L.qpos + i]; o += m.nq; }
+  if (s.flags & 2) { for (int i = lane; i < m.nv; i += G) out[o + i] = (TS)w[L.qvel + i]; o += m.nv; }
+  if (s.flags & 8) { for (int i = lane; i < m.nsensordata; i += G) out[o + i] = (TS)0; o += m.nsensordata; }
+  for (int i = lane; i < 3 * s.nsite; i += G) out[o + i] = (TS)w[L.site_xpos + 3 * s.site_ids[i / 3] + i % 3];
+  o += 3 * s.nsite;
+  for (int i = lane; i < 3 * s.nsubtree; i += G) out[o + i] = (TS)w[L.subtree_com + 3 * s.subtree_ids[i / 3] + i % 3];
+  o += 3 * s.nsubtree;
+  if (s.flags & 16) { if (lane == 0) out[o] = (TS)time; o += 1; }
+}
+
+// ---------------------------------------------------------------------------
+// the per-environment driver: load -> nstep x (ctrl, forward, integrate) -> store
+// ---------------------------------------------------------------------------
+template <typename T, typename TS, int G>
+MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
+                     const ObsSpecDev& obs, TS* obs_out, T* w, int* wi, int env, int lane) {
+  Ctx<T> c(m, L, w, wi, lane);
+  const int nq = m.nq, nv = m.nv, nu = m.nu;
+  for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
+  for (int i = lane; i < nv; i += G) {
+    w[L.qvel + i] = (T)d.qvel[(size_t)env * nv + i];
+    w[L.qacc_ws + i] = (T)d.qacc_warmstart[(size_t)env * nv + i];
+    w[L.qacc + i] = (T)d.qacc[(size_t)env * nv + i];
+  }
+  for (int i = lane; i < nu; i += G) w[L.ctrl + i] = a.ctrl_mode == CTRL_ZERO ? (T)0 : (T)d.ctrl[(size_t)env * nu + i];
+  double time = d.time[env];
+  int badqpos = 0, badqvel = 0, badqacc = 0;
+  gsync<G>();
+  const int nstep = a.mode == 1 ? 1 : a.nstep;
+  for (int s = 0; s < nstep; s++) {
+    if (a.mode == 0) {
+      if (group_bad<T, G>(w + L.qpos, nq, lane)) { badqpos++; reset_state<T, G>(c); time = 0; }
+      if (group_bad<T, G>(w + L.qvel, nv, lane)) { badqvel++; reset_state<T, G>(c); time = 0; }
+      if (a.ctrl_mode == CTRL_RANDOM) {
+        random_ctrl<T, G>(m, w + L.ctrl, a.seed, a.env0 + (unsigned)env, a.step0 + (unsigned)s, (T)a.ctrl_scale, lane);
+        gsync<G>();
+      }
+    }
+    forward<T, G>(c);
+    if (a.mode == 1) break;
+    if (group_bad<T, G>(w + L.qacc, nv, lane)) { badqacc++; reset_state<T, G>(c); time = 0; forward<T, G>(c); }
+    if (m.integrator == INT_RK4) rk4<T, G>(c); else euler<T, G>(c);
+    time += (double)m.timestep;
+    if (a.obs_every > 0 && ((s + 1) % a.obs_every) == 0) {
+      size_t slot = (size_t)((s + 1) / a.obs_every - 1);
+      write_obs<T, TS, G>(c, obs, time, obs_out + (slot * (size_t)d.batch + (size_t)env) * (size_t)obs.dim);
+    }
+  }
+  // store state
+  for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
+  for (int i = lane; i < nv; i += G) {
+    d.qvel[(size_t)env * nv + i] = (TS)w[L.qvel + i];
+    d.qacc[(size_t)env * nv + i] = (TS)w[L.qacc + i];
+    d.qacc_warmstart[(size_t)env * nv + i] = (TS)w[L.qacc_ws + i];
+  }
+  if (a.ctrl_mode != CTRL_KEEP) for (int i = lane; i < nu; i += G) d.ctrl[(size_t)env * nu + i] = (TS)w[L.ctrl + i];
+  if (lane == 0) {
+    d.time[env] = time;
+    int* cn = d.counters + (size_t)env * CNT_N;
+    cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
+    cn[CNT_CON_DROPPED] += c.con_dropped; cn[CNT_EFC_DROPPED] += c.efc_dropped;
+    cn[CNT_BADQPOS] += badqpos; cn[CNT_BADQVEL] += badqvel; cn[CNT_BADQACC] += badqacc;
+  }
+  if (a.write_kin) {
+    for (int i = lane; i < 3 * m.nbody; i += G) {
+      d.xpos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xpos + i];
+      d.xipos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xipos + i];
+      d.subtree_com[(size_t)env * 3 * m.nbody + i] = (TS)w[L.subtree_com + i];
+    }
+    for (int i = lane; i < 4 * m.nbody; i += G) d.xquat[(size_t)env * 4 * m.nbody + i] = (TS)w[L.xquat + i];
+    for (int i = lane; i < 3 * m.nsite; i += G) d.site_xpos[(size_t)env * 3 * m.nsite + i] = (TS)w[L.site_xpos + i];
+    for (int i = lane; i < 3 * m.ngeom; i += G) d.geom_xpos[(size_t)env * 3 * m.ngeom + i] = (TS)w[L.geom_xpos + i];
+  }
+  // optional per-phase dumps (forward mode, parity tests)
+  if (dbg.qM) for (int i = lane; i < nv * nv; i += G) dbg.qM[(size_t)env * nv * nv + i] = (TS)w[L.M + i];
+  if (dbg.qfrc_bias) for (int i = lane; i < nv; i += G) {
+    dbg.qfrc_bias[(size_t)env * nv + i] = (TS)w[L.qfrc_bias + i];
+    dbg.qfrc_passive[(size_t)env * nv + i] = (TS)w[L.qfrc_passive + i];
+    dbg.qfrc_actuator[(size_t)env * nv + i] = (TS)w[L.qfrc_actuator + i];
+    dbg.qacc_smooth[(size_t)env * nv + i] = (TS)w[L.qacc_smooth + i];
+    dbg.qfrc_constraint[(size_t)env * nv + i] = (TS)w[L.qfrc_constraint + i];
+  }
+  if (dbg.efc_J) {
+    size_t ne = (size_t)m.nefc_max;
+    for (int i = lane; i < c.nefc * nv; i += G) dbg.efc_J[(size_t)env * ne * nv + i] = (TS)w[L.efc_J + i];
+    for (int i = lane; i < c.nefc; i += G) {
+      dbg.efc_aref[(size_t)env * ne + i] = (TS)w[L.efc_aref + i];
+      dbg.efc_D[(size_t)env * ne + i] = (TS)w[L.efc_D + i];
+      dbg.efc_pos[(size_t)env * ne + i] = (TS)w[L.efc_pos + i];
+      dbg.efc_force[(size_t)env * ne + i] = (TS)w[L.efc_force + i];
+      dbg.efc_type[(size_t)env * ne + i] = wi[L.i_efc_type + i];
+    }
+  }
+  if (dbg.con) for (int i = lane; i < c.ncon * CON_STRIDE; i += G) dbg.con[(size_t)env * m.ncon_max * CON_STRIDE + i] = (TS)w[L.con + i];
+  if (dbg.cdof) {
+    for (int i = lane; i < 6 * nv; i += G) dbg.cdof[(size_t)env * 6 * nv + i] = (TS)w[L.cdof + i];
+    for (int i = lane; i < 10 * m.nbody; i += G) dbg.cinert[(size_t)env * 10 * m.nbody + i] = (TS)w[L.cinert + i];
+    for (int i = lane; i < 6 * m.nbody; i += G) dbg.cvel[(size_t)env * 6 * m.nbody + i] = (TS)w[L.cvel + i];
+  }
+}
+
+}  // namespace mjb

@@ -1,0 +1,116 @@
+// mjb_types.hpp — structures shared by the host API and the device kernels.
+//
+// DevModel<T>: the compiled model as device pointers (T = float for the product
+// path, double for the finite-difference / validation path).  Passed BY VALUE as
+// a kernel argument, so the pointers arrive in SGPRs through the kernarg segment.
+// Lay: per-environment LDS layout (offsets in elements of T / int), computed on
+// the host from the model sizes and the contact/constraint caps.
+#pragma once
+#include <cstdint>
+
+namespace mjb {
+
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
+enum { TRN_JOINT = 0, TRN_SITE = 4 };
+enum { INT_EULER = 0, INT_RK4 = 1 };
+enum { SENS_JOINTPOS = 0, SENS_GYRO, SENS_ACCEL, SENS_FRAMEQUAT };
+enum { EFC_LIMIT_JOINT = 0, EFC_LIMIT_TENDON = 1, EFC_CONTACT_FRICTIONLESS = 2, EFC_CONTACT_PYRAMIDAL = 3 };
+enum { CTRL_KEEP = 0, CTRL_ZERO = 1, CTRL_RANDOM = 2 };
+
+// counters written per environment (int[8])
+enum { CNT_NCON = 0, CNT_NEFC, CNT_NITER, CNT_CON_DROPPED, CNT_EFC_DROPPED, CNT_BADQPOS, CNT_BADQVEL, CNT_BADQACC, CNT_N };
+
+template <typename T>
+struct DevModel {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nsensor, nsensordata, nkey, npair;
+  int nlevel, integrator, disableactuator, iterations, has_damping, has_fluid, nvp, nvshift;
+  int ncon_max, nefc_max;
+  T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
+  // kinematic tree
+  const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
+  const int *level_adr, *level_body, *child_adr, *child_id;
+  const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_subtreemass, *body_invweight0;
+  const unsigned long long *body_dofmask, *dof_ancmask;
+  // joints / dofs
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const T *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_margin, *jnt_solref, *jnt_solimp, *qpos0, *qpos_spring;
+  const int *dof_bodyid, *dof_jntid, *dof_parentid;
+  const T *dof_armature, *dof_damping, *dof_invweight0;
+  // geoms / sites
+  const int *geom_type, *geom_bodyid;
+  const T *geom_pos, *geom_quat, *geom_size;
+  const int* site_bodyid;
+  const T *site_pos, *site_quat;
+  // tendons
+  const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
+  const T *tendon_range, *tendon_margin, *tendon_solref, *tendon_solimp, *tendon_invweight0, *wrap_prm;
+  // actuators
+  const int *actuator_trntype, *actuator_trnid, *actuator_biastype, *actuator_ctrllimited, *actuator_forcelimited, *actuator_group;
+  const T *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  // sensors
+  const int *sensor_type, *sensor_objid, *sensor_adr;
+  // collision pairs
+  const int *pair_geom1, *pair_geom2, *pair_condim;
+  const T *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  // keyframes
+  const T *key_qpos, *key_qvel, *key_ctrl, *key_time;
+};
+
+// Per-environment LDS layout.  Offsets of T arrays are in units of T from the
+// environment's base; int arrays are in units of int from the int base (placed
+// after the nT T-elements).
+struct Lay {
+  int qpos, qvel, ctrl, qacc, qacc_ws, qacc_smooth;
+  int qfrc_bias, qfrc_passive, qfrc_actuator, qfrc_smooth, qfrc_constraint;
+  int xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, geom_xpos, geom_xmat, site_xpos, site_xmat;
+  int subtree_com, cinert, crb, cdof, cdof_dot, cvel, cacc, cfrc, dofbuf, bfrc;
+  int M, W, ten_length, ten_J, act_force;
+  int con;            // contacts: ncon_max * CON_STRIDE
+  int efc_J, efc_pos, efc_D, efc_aref, efc_jar, efc_jv, efc_force, efc_KBI;
+  int Ma, grad, search, Mv, tmp;
+  int rk;             // RK4 scratch: X0 (nq+nv) + F (4*2*nv) + dX (2*nv)
+  int nT;             // total T elements
+  int i_efc_type, i_efc_id, i_con_pair, i_scal;  // int arrays
+  int nI;             // total ints
+  int bytes;          // total bytes per environment (rounded to 16)
+};
+
+constexpr int CON_STRIDE = 14;  // dist, pos[3], frame[9], mu(friction[0]) ; pair id in i_con_pair
+
+// Device state of the batch (TS = storage type of the [batch, dof] arrays in HBM).
+template <typename TS>
+struct DevData {
+  int batch;
+  TS *qpos, *qvel, *ctrl, *qacc, *qacc_warmstart;
+  double* time;
+  TS *xpos, *xquat, *xipos, *site_xpos, *geom_xpos, *subtree_com, *sensordata;
+  int* counters;
+};
+
+// optional per-phase dumps for parity tests (device pointers, may be null)
+template <typename TS>
+struct DevDebug {
+  TS *qM, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qacc_smooth, *qfrc_constraint;
+  TS *efc_J, *efc_aref, *efc_D, *efc_pos, *efc_force, *con;
+  TS *cdof, *cinert, *cvel;
+  int *efc_type;
+};
+
+struct ObsSpecDev {
+  int flags;        // bit0 qpos, bit1 qvel, bit2 ctrl, bit3 sensordata, bit4 time, bit5 act(empty), bit6 bodies_inertial
+  int nsite, nbody, ngeom, nsubtree, dim;
+  const int *site_ids, *body_ids, *geom_ids, *subtree_ids;
+};
+
+struct StepArgs {
+  int nstep;
+  int ctrl_mode;         // CTRL_*
+  unsigned seed, step0, env0;   // env0 = global index of this shard's first env (RNG is shard-invariant)
+  float ctrl_scale;
+  int mode;              // 0 = step, 1 = forward only
+  int write_kin;         // write xpos/xipos/site_xpos/geom_xpos/subtree_com/sensordata of the last forward pass
+  int obs_every;         // >0: write flat obs every k steps into obs_out[(step/k), env, dim]
+};
+
+}  // namespace mjb
