@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the batched step/rollout path (BASELINE.json).
+
+Workload (config[2] of BASELINE.json, the one the metric is quoted on): the reference's
+``examples/humanoid`` model, random-ctrl rollout, GLOBAL batch 4096 sharded over the ranks
+(one process per GPU, no collective on the stepping path), fp32 state, flat observation
+(qpos ‖ qvel, the default ObservationSpec of Env.from_xml_path) all-gathered over RCCL once
+per fused chunk.  One bench "step" = one simulation step of the whole global batch.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torchrun)
+
+Prints ONE JSON line (rank 0).  ``value`` = env-steps / s of the whole job with inputs resident
+in HBM; ``roofline`` prices the dominant kernel (k_step) against HBM with the algorithmic
+bytes of SURVEY.md §8(d); ``cpu_baseline`` times the float64 oracle (a port: the reference's
+own CPU path needs the absent ``mujoco`` wheel) on the host cores for a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--global-batch", type=int, default=4096)
+    ap.add_argument("--chunk", type=int, default=100, help="simulation steps fused per kernel launch")
+    ap.add_argument("--weak", action="store_true", help="fixed per-GPU batch (= --global-batch per rank) instead of sharding it")
+    ap.add_argument("--model", default="humanoid", choices=["humanoid", "cartpole", "drone2", "pendulum"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nefcmax", type=int, default=0)
+    ap.add_argument("--nconmax", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from mujoco_template_amd import Env, ObservationSpec, RandomCtrlController
+    from mujoco_template_amd.distributed import all_gather_obs, init_process_group, shard_range, world
+
+    rank, ws, local = world()
+    if ws != args.gpus:
+        if rank == 0 and ws > 1:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={ws}; using WORLD_SIZE", file=sys.stderr)
+    distributed = init_process_group("nccl") if ws > 1 else False
+    device = local if ws > 1 else 0
+    torch.cuda.set_device(device)
+
+    xml = {"humanoid": "models/humanoid.xml", "cartpole": "models/cartpole.xml", "drone2": "models/drone2/scene.xml",
+           "pendulum": "models/pendulum.xml"}[args.model]
+    scale = {"humanoid": 1.0, "cartpole": 0.005, "drone2": 0.3, "pendulum": 1.0}[args.model]
+    if args.weak:
+        env0, count = rank * args.global_batch, args.global_batch
+        global_batch = args.global_batch * ws
+    else:
+        env0, count = shard_range(args.global_batch, rank, ws)
+        global_batch = args.global_batch
+
+    env = Env.from_xml_path(os.path.join(ROOT, xml), obs_spec=ObservationSpec(as_dict=False),
+                            controller=RandomCtrlController(seed=0, scale=scale), batch=count, dtype="float32", device=device,
+                            env0=env0, nefcmax=args.nefcmax, nconmax=args.nconmax)
+    sim = env.data.sim
+    sim.use_torch_stream()
+    obs_dim = env.extractor.obs_dim
+    nq, nv, nu = env.model.nq, env.model.nv, env.model.nu
+
+    def run(nsteps: int, events=None) -> None:
+        done = 0
+        while done < nsteps:
+            n = min(args.chunk, nsteps - done)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            obs = env.rollout(n, obs_every=n)             # [1, b_local, obs_dim] on the GPU
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, n))
+            all_gather_obs(obs)                            # RCCL all-gather of the ObservationExtractor output
+            done += n
+
+    def barrier() -> None:
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    events: list = []
+    t0 = time.perf_counter()
+    run(args.steps, events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], device=f"cuda:{device}", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    counters = env.data.counters()
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    steps_per_launch = [n for _, _, n in events]
+
+    if rank == 0:
+        value = global_batch * args.steps / elapsed
+        # algorithmic bytes per env-step (fp32): state read+write, ctrl, warm-start read+write, + obs when gathered
+        bytes_step = 4 * ((nq + nv) * 2 + nu + 2 * nv)
+        bytes_obs = 4 * obs_dim
+        avg_ms = float(np.mean(kernel_ms))
+        avg_steps = float(np.mean(steps_per_launch))
+        launch_bytes = count * (bytes_step * avg_steps + bytes_obs)          # one obs row per env per launch
+        achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), humanoid batch=4096 random-ctrl rollout" if args.model == "humanoid"
+                      else f"env-steps/sec (whole node), {args.model} random-ctrl rollout",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": ws,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "wall_ms_per_1000_step_rollout": elapsed * 1e3 / args.steps * 1000.0,
+            "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (qpos0 start, Philox uniform random ctrl over ctrlrange, seed 0)",
+            "config": {"workload": f"examples/{args.model} random-ctrl rollout (BASELINE.json configs[2])" if args.model == "humanoid"
+                       else f"examples/{args.model} random-ctrl rollout",
+                       "global_batch": global_batch, "per_gpu_batch": count, "rollout_steps": args.steps,
+                       "fused_steps_per_launch": args.chunk, "obs_dim": obs_dim, "parallelism": f"env-shard x{ws}",
+                       "lanes_per_env": sim.lanes, "lds_bytes_per_env": sim.lds_bytes_per_env,
+                       "nefcmax": sim.nefcmax, "nconmax": sim.nconmax},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mjb::k_step<float,float,%d>" % sim.lanes,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_env_step": bytes_step, "obs_bytes_per_env": bytes_obs,
+                         "note": "fused step is VALU/LDS-latency bound by construction (SURVEY.md §8d); see DESIGN.md for VALU/LDS counters"},
+            "solver": {"mean_nefc_last_step": float(counters["nefc"].mean()), "max_nefc_last_step": int(counters["nefc"].max()),
+                       "mean_newton_iters_last_step": float(counters["solver_niter"].mean()),
+                       "dropped_contacts": int(counters["con_dropped"].sum()), "dropped_rows": int(counters["efc_dropped"].sum()),
+                       "bad_state_resets": int(counters["warn_badqpos"].sum() + counters["warn_badqvel"].sum() + counters["warn_badqacc"].sum())},
+        }
+        if ws == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, xml), scale)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(xml_path: str, scale: float) -> dict:
+    """Bounded sample of the same workload on the host cores with the float64 oracle (kind = "port")."""
+    from mujoco_template_amd.mjcf import compile_xml_path
+    from oracle import mjo
+
+    om = mjo.OracleModel(compile_xml_path(xml_path))
+    cores = min(os.cpu_count() or 1, 16)
+    mjo.rollout_batch(om, cores, 20, seed=0, scale=scale, nthreads=cores)          # warm-up
+    nenv, nstep = 8 * cores, 500
+    t = time.perf_counter()
+    mjo.rollout_batch(om, nenv, nstep, seed=0, scale=scale, nthreads=cores)
+    dt = time.perf_counter() - t
+    t1 = time.perf_counter()
+    mjo.rollout_batch(om, 4, nstep, seed=0, scale=scale, nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {"value": nenv * nstep / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_core_value": 4 * nstep / dt1,
+            "sample": f"{nenv} envs x {nstep} steps of the same random-ctrl rollout, float64 C oracle, one env per OpenMP task; "
+                      "the reference's own CPU loop (mujoco wheel) is not runnable here"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""Built-in controllers.  ``ZeroController`` and ``PositionTargetDemo`` follow the reference
+(``mujoco_template/controllers.py:12-46``); ``RandomCtrlController`` is the synthetic
+random-ctrl driver of BASELINE.json's rollout configs.  Zero and random run on the device
+(``device_ctrl_mode``), and their host ``__call__`` writes exactly the same values.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from .control import ControlSpace, ControllerCapabilities
+from .exceptions import CompatibilityError, ConfigError, TemplateError
+
+
+def _ctrl_rows(data: Any) -> np.ndarray:
+    ctrl = data.ctrl
+    return ctrl.reshape(1, -1) if ctrl.ndim == 1 else ctrl
+
+
+@dataclass
+class ZeroController:
+    capabilities: ControllerCapabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
+    device_ctrl_mode: str = "zero"
+
+    def prepare(self, model: Any, data: Any) -> None:
+        if model.nu == 0:
+            raise CompatibilityError("ZeroController requires nu>0 to write controls.")
+
+    def __call__(self, model: Any, data: Any, t: float) -> None:
+        if _ctrl_rows(data).shape[-1] != model.nu:
+            raise TemplateError("data.ctrl size does not match model.nu")
+        data.ctrl[...] = 0.0
+
+
+@dataclass
+class PositionTargetDemo:
+    targets: np.ndarray | None = None
+    capabilities: ControllerCapabilities = ControllerCapabilities(control_space=ControlSpace.POSITION)
+
+    def prepare(self, model: Any, data: Any) -> None:
+        if model.nu == 0:
+            raise CompatibilityError("PositionTargetDemo requires nu>0.")
+        if self.targets is None:
+            row = _ctrl_rows(data)[0]
+            self.targets = np.array(row) if row.size == model.nu else np.zeros(model.nu)
+        if self.targets.shape[-1] != model.nu:
+            raise ConfigError("targets must have length model.nu")
+
+    def __call__(self, model: Any, data: Any, t: float) -> None:
+        if _ctrl_rows(data).shape[-1] != model.nu:
+            raise TemplateError("data.ctrl size does not match model.nu")
+        data.ctrl[...] = self.targets
+
+
+def philox_uniform(seed: int, env: np.ndarray, step: int, nu: int) -> np.ndarray:
+    """u[env, actuator] in [0,1): Philox4x32-10 keyed by (seed, 0x5EED), counter (env, step, actuator, 0).
+
+    Bit-identical to ``philox_first`` in ``csrc/mjb_device.hpp``.
+    """
+    c0 = np.repeat(np.asarray(env, dtype=np.uint64)[:, None], nu, axis=1) & 0xFFFFFFFF
+    c1 = np.full_like(c0, step & 0xFFFFFFFF)
+    c2 = np.broadcast_to(np.arange(nu, dtype=np.uint64)[None, :], c0.shape).copy()
+    c3 = np.zeros_like(c0)
+    k0, k1 = seed & 0xFFFFFFFF, 0x5EED
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & mask
+        n3 = p0 & mask
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
+        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return (c0 >> np.uint64(8)).astype(np.float64) / 16777216.0
+
+
+@dataclass
+class RandomCtrlController:
+    """ctrl[a] = mid + half * scale * (2u - 1), u ~ Philox(seed; global env index, step, a)."""
+
+    seed: int = 0
+    scale: float = 1.0
+    capabilities: ControllerCapabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
+    device_ctrl_mode: str = "random"
+    step_count: int = field(default=0)
+    env0: int = 0
+
+    def prepare(self, model: Any, data: Any) -> None:
+        if model.nu == 0:
+            raise CompatibilityError("RandomCtrlController requires nu>0 to write controls.")
+        self.step_count = 0
+
+    def __call__(self, model: Any, data: Any, t: float) -> None:
+        rows = _ctrl_rows(data)
+        env = np.arange(rows.shape[0]) + self.env0
+        u = philox_uniform(self.seed, env, self.step_count, model.nu)
+        lo = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 0], -1.0)
+        hi = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 1], 1.0)
+        rows[...] = 0.5 * (lo + hi) + 0.5 * (hi - lo) * self.scale * (2.0 * u - 1.0)
+        self.step_count += 1
+
+
+__all__ = ["ZeroController", "PositionTargetDemo", "RandomCtrlController", "philox_uniform"]

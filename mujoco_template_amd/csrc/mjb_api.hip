@@ -59,7 +59,7 @@ struct mjbObsSpec {
 
 struct mjbData {
   mjbModel* model;
-  int batch, dtype, G, ncon_max, nefc_max, device, env0;
+  int batch, dtype, G, G_fd, ncon_max, nefc_max, device, env0;
   hipStream_t stream;
   DevAlloc alloc;
   DevModel<float> mf;
@@ -225,8 +225,11 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
   if (!d->alloc.ok) { mjb_data_free(d); return fail(MJB_ERR_DEVICE, "device allocation of the model failed"); }
   d->Lf = make_layout(h, d->ncon_max, d->nefc_max, sizeof(float));
   d->Ld = make_layout(h, d->ncon_max, d->nefc_max, sizeof(double));
-  size_t lds = (size_t)(64 / d->G) * (size_t)d->Ld.bytes;
-  if (lds > 160 * 1024) {
+  // the float64 FD / Jacobian kernels may need more lanes per environment than the step kernel to fit LDS
+  d->G_fd = d->G;
+  while (d->G_fd < 64 && (size_t)(64 / d->G_fd) * (size_t)d->Ld.bytes > 160 * 1024) d->G_fd = d->G_fd == 8 ? 16 : 64;
+  size_t lds = (size_t)(64 / d->G) * (size_t)(dtype == MJB_F32 ? d->Lf.bytes : d->Ld.bytes);
+  if (lds > 160 * 1024 || (size_t)(64 / d->G_fd) * (size_t)d->Ld.bytes > 160 * 1024) {
     char buf[256];
     std::snprintf(buf, sizeof buf, "per-workgroup LDS %zu B exceeds 160 KiB (lower nconmax/nefcmax or use more lanes)", lds);
     mjb_data_free(d);
@@ -429,8 +432,8 @@ int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, doub
         dev_alloc(d, &d->fd_A, B * nx * nx) || dev_alloc(d, &d->fd_B, B * nx * (h.nu > 0 ? h.nu : 1)))
       return fail(MJB_ERR_DEVICE, "device allocation of FD scratch failed");
   }
-  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G, d->md, d->Ld, d->df, ncol, eps, d->fd_y, d->fd_valid, d->stream)
-                                     : launch_fd<double, double>(d->G, d->md, d->Ld, d->dd, ncol, eps, d->fd_y, d->fd_valid, d->stream);
+  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md, d->Ld, d->df, ncol, eps, d->fd_y, d->fd_valid, d->stream)
+                                     : launch_fd<double, double>(d->G_fd, d->md, d->Ld, d->dd, ncol, eps, d->fd_y, d->fd_valid, d->stream);
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("fd launch: ") + hipGetErrorString(e));
   long nthreads = (long)B * nin;
   hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, d->md, d->batch, ncol, centered, eps,
@@ -459,8 +462,8 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
   HIPCHK(hipMalloc((void**)&di, sizeof(int) * nreq));
   HIPCHK(hipMemcpy(dk, kinds, sizeof(int) * nreq, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(di, ids, sizeof(int) * nreq, hipMemcpyHostToDevice));
-  hipError_t e = d->dtype == MJB_F32 ? launch_jac<double, float>(d->G, d->md, d->Ld, d->df, nreq, dk, di, op, orr, d->stream)
-                                     : launch_jac<double, double>(d->G, d->md, d->Ld, d->dd, nreq, dk, di, op, orr, d->stream);
+  hipError_t e = d->dtype == MJB_F32 ? launch_jac<double, float>(d->G_fd, d->md, d->Ld, d->df, nreq, dk, di, op, orr, d->stream)
+                                     : launch_jac<double, double>(d->G_fd, d->md, d->Ld, d->dd, nreq, dk, di, op, orr, d->stream);
   int rc = MJB_OK;
   if (e != hipSuccess) rc = fail(MJB_ERR_DEVICE, std::string("jac launch: ") + hipGetErrorString(e));
   if (rc == MJB_OK && hipStreamSynchronize(d->stream) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac sync failed");

@@ -194,18 +194,16 @@ template <typename T> MJB_DEV void cross_force(T* res, const T* vel, const T* f)
   res[5] = -vel[1] * f[3] + vel[0] * f[4];
 }
 
-// triangle enumeration idx -> (r, c), 0 <= c <= r, idx = r(r+1)/2 + c (exact for idx < 2^22)
-MJB_DEV void tri_rc(int idx, int& r, int& c) {
-  int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-  while ((rr + 1) * (rr + 2) / 2 <= idx) rr++;
-  while (rr * (rr + 1) / 2 > idx) rr--;
-  r = rr; c = idx - rr * (rr + 1) / 2;
+// triangle enumeration idx -> (r, c), 0 <= c <= r, idx = r(r+1)/2 + c: host-built table (r << 16 | c)
+MJB_DEV void tri_rc(const int* tab, int idx, int& r, int& c) {
+  int v = tab[idx];
+  r = v >> 16; c = v & 0xffff;
 }
 
 // ---------------------------------------------------------------------------
 // dense Cholesky in LDS (lower triangle, in place) + solve.  dinv receives 1/L[j][j].
 // ---------------------------------------------------------------------------
-template <typename T, int G> MJB_DEV void chol_factor(T* A, T* dinv, int n, int lane) {
+template <typename T, int G> MJB_DEV void chol_factor(T* A, T* dinv, int n, int lane, const int* tri) {
   for (int j = 0; j < n; j++) {
     gsync<G>();
     T ajj = A[j * n + j];
@@ -218,7 +216,7 @@ template <typename T, int G> MJB_DEV void chol_factor(T* A, T* dinv, int n, int 
     int t = n - 1 - j, np = t * (t + 1) / 2;
     for (int idx = lane; idx < np; idx += G) {
       int r, c;
-      tri_rc(idx, r, c);
+      tri_rc(tri, idx, r, c);
       int i = j + 1 + r, k = j + 1 + c;
       A[i * n + k] -= A[i * n + j] * A[k * n + j];
     }
@@ -533,7 +531,7 @@ template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
     W[i * nv + j] = val;
   }
   gsync<G>();
-  chol_factor<T, G>(W, w + L.tmp, nv, lane);
+  chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
 }
 
 // ---------------------------------------------------------------------------
@@ -1128,7 +1126,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c) {
   int np = nv * (nv + 1) / 2;
   for (int idx = lane; idx < np; idx += G) {
     int i, k;
-    tri_rc(idx, i, k);
+    tri_rc(m.tri_tab, idx, i, k);
     T h = M[i * nv + k];
     for (int r = 0; r < nefc; r++) {
       T d = dw[r];
@@ -1137,7 +1135,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c) {
     W[i * nv + k] = h;
   }
   gsync<G>();
-  chol_factor<T, G>(W, w + L.tmp, nv, lane);
+  chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
   chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
   for (int i = lane; i < nv; i += G) search[i] = -search[i];
   gsync<G>();
@@ -1155,28 +1153,34 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   }
   T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *jv = w + L.efc_jv, *D = w + L.efc_D, *force = w + L.efc_force;
   T *search = w + L.search, *Mv = w + L.Mv, *qs = w + L.qfrc_smooth;
-  T cost_ws = solver_cost<T, G>(c, ws, false);
-  T cost_sm = solver_cost<T, G>(c, qas, false);
-  bool use_ws = cost_ws < cost_sm;
-  for (int i = lane; i < nv; i += G) qacc[i] = use_ws ? ws[i] : qas[i];
+  // warmstart(): best of (qacc_warmstart, qacc_smooth).  pass 0: warmstart, pass 1: smooth, pass 2: warmstart again if it won
+  T cost = 0, cost_ws = 0;
+  for (int pass = 0; pass < 3; pass++) {
+    const T* x = pass == 1 ? qas : ws;
+    T cst = solver_cost<T, G>(c, x, true);
+    if (pass == 0) cost_ws = cst;
+    else if (pass == 1) {
+      cost = cst;
+      if (!(cost_ws < cst)) { for (int i = lane; i < nv; i += G) qacc[i] = qas[i]; break; }
+    } else { cost = cst; for (int i = lane; i < nv; i += G) qacc[i] = ws[i]; }
+  }
   gsync<G>();
-  T cost = solver_cost<T, G>(c, qacc, true);
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
-  T gn = newton_direction<T, G>(c);
   for (int iter = 0; iter < m.iterations; iter++) {
+    T gn = newton_direction<T, G>(c);
     if (scale * t_sqrt(gn) < m.tolerance) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
     for (int i = lane; i < nv; i += G) {
-      T s = 0;
-      for (int k = 0; k < nv; k++) s += M[i * nv + k] * search[k];
-      Mv[i] = s;
-      p1 += search[i] * (Ma[i] - qs[i]); p2 += search[i] * s;
+      T sacc = 0;
+      for (int k = 0; k < nv; k++) sacc += M[i * nv + k] * search[k];
+      Mv[i] = sacc;
+      p1 += search[i] * (Ma[i] - qs[i]); p2 += search[i] * sacc;
     }
     for (int r = lane; r < nefc; r += G) {
-      T s = 0;
-      for (int k = 0; k < nv; k++) s += J[r * nv + k] * search[k];
-      jv[r] = s;
+      T sacc = 0;
+      for (int k = 0; k < nv; k++) sacc += J[r * nv + k] * search[k];
+      jv[r] = sacc;
     }
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
     gsync<G>();
@@ -1206,21 +1210,20 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
       part += (T)0.5 * (ma - qs[i]) * (a - qas[i]);
     }
     for (int r = lane; r < nefc; r += G) {
-      T s = jar[r] + alpha * jv[r];
-      jar[r] = s;
-      if (s < 0) { part += (T)0.5 * D[r] * s * s; force[r] = -D[r] * s; } else force[r] = 0;
+      T sj = jar[r] + alpha * jv[r];
+      jar[r] = sj;
+      if (sj < 0) { part += (T)0.5 * D[r] * sj * sj; force[r] = -D[r] * sj; } else force[r] = 0;
     }
     T old = cost;
     cost = gsum<T, G>(part);
     gsync<G>();
     c.niter = iter + 1;
-    gn = newton_direction<T, G>(c);
     if (scale * (old - cost) < m.tolerance) break;
   }
   for (int i = lane; i < nv; i += G) {
-    T s = 0;
-    for (int r = 0; r < nefc; r++) s += J[r * nv + i] * force[r];
-    qc[i] = s; ws[i] = qacc[i];
+    T sacc = 0;
+    for (int r = 0; r < nefc; r++) sacc += J[r * nv + i] * force[r];
+    qc[i] = sacc; ws[i] = qacc[i];
   }
   gsync<G>();
 }
@@ -1263,11 +1266,11 @@ template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
     int np = nv * (nv + 1) / 2;
     for (int idx = lane; idx < np; idx += G) {
       int i, k;
-      tri_rc(idx, i, k);
+      tri_rc(m.tri_tab, idx, i, k);
       W[i * nv + k] = M[i * nv + k] + (i == k ? h * m.dof_damping[i] : (T)0);
     }
     gsync<G>();
-    chol_factor<T, G>(W, w + L.tmp, nv, lane);
+    chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
     chol_solve<T, G>(W, w + L.tmp, tmpv, nv, lane);
   } else {
     for (int i = lane; i < nv; i += G) tmpv[i] = qacc[i];
@@ -1279,33 +1282,27 @@ template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
   gsync<G>();
 }
 
-// A11 RK4 (mj_RungeKutta, N = 4).  rk scratch: X0q[nq] X0v[nv] Fv[4nv] Fa[4nv] dv[nv] da[nv]
-template <typename T, int G> MJB_DEV void rk4(Ctx<T>& c) {
+// A11 RK4 (mj_RungeKutta, N = 4) as a stage machine so that forward() has a single call site.
+// rk scratch: X0q[nq] X0v[nv] Fv[4nv] Fa[4nv] dv[nv].  Call after the forward pass of stage st (0..3).
+template <typename T, int G> MJB_DEV void rk4_stage(Ctx<T>& c, int st) {
   const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nq = m.nq;
   T *qacc = w + L.qacc, *qvel = w + L.qvel, *qpos = w + L.qpos;
-  T *X0q = w + L.rk, *X0v = X0q + nq, *Fv = X0v + nv, *Fa = Fv + 4 * nv, *dv = Fa + 4 * nv, *da = dv + nv;
+  T *X0q = w + L.rk, *X0v = X0q + nq, *Fv = X0v + nv, *Fa = Fv + 4 * nv, *dv = Fa + 4 * nv;
   const T h = m.timestep;
-  const T A[9] = {(T)0.5, 0, 0, 0, (T)0.5, 0, 0, 0, 1}, Bc[4] = {(T)(1.0 / 6), (T)(1.0 / 3), (T)(1.0 / 3), (T)(1.0 / 6)};
-  for (int i = lane; i < nq; i += G) X0q[i] = qpos[i];
-  for (int i = lane; i < nv; i += G) { X0v[i] = qvel[i]; Fv[i] = qvel[i]; Fa[i] = qacc[i]; }
-  gsync<G>();
-  for (int st = 1; st < 4; st++) {
-    for (int i = lane; i < nv; i += G) {
-      T sv = 0, sa = 0;
-      for (int j = 0; j < 3; j++) { T a = A[(st - 1) * 3 + j]; if (a != 0) { sv += a * Fv[j * nv + i]; sa += a * Fa[j * nv + i]; } }
-      dv[i] = sv; qvel[i] = X0v[i] + h * sa;
-    }
-    for (int i = lane; i < nq; i += G) qpos[i] = X0q[i];
-    gsync<G>();
-    integrate_pos<T, G>(m, qpos, dv, h, lane);
-    gsync<G>();
-    forward<T, G>(c);
-    for (int i = lane; i < nv; i += G) { Fv[st * nv + i] = qvel[i]; Fa[st * nv + i] = qacc[i]; }
-    gsync<G>();
+  if (st == 0) {
+    for (int i = lane; i < nq; i += G) X0q[i] = qpos[i];
+    for (int i = lane; i < nv; i += G) X0v[i] = qvel[i];
   }
+  for (int i = lane; i < nv; i += G) { Fv[st * nv + i] = qvel[i]; Fa[st * nv + i] = qacc[i]; }
+  gsync<G>();
+  // tableau: stage st+1 state uses row st of A = [[1/2],[0,1/2],[0,0,1]]; the last stage combines with B = [1/6,1/3,1/3,1/6]
   for (int i = lane; i < nv; i += G) {
-    T sv = 0, sa = 0;
-    for (int j = 0; j < 4; j++) { sv += Bc[j] * Fv[j * nv + i]; sa += Bc[j] * Fa[j * nv + i]; }
+    T sv, sa;
+    if (st < 3) { T a = st == 2 ? (T)1 : (T)0.5; sv = a * Fv[st * nv + i]; sa = a * Fa[st * nv + i]; }
+    else {
+      sv = (Fv[i] + 2 * Fv[nv + i] + 2 * Fv[2 * nv + i] + Fv[3 * nv + i]) * (T)(1.0 / 6);
+      sa = (Fa[i] + 2 * Fa[nv + i] + 2 * Fa[2 * nv + i] + Fa[3 * nv + i]) * (T)(1.0 / 6);
+    }
     dv[i] = sv; qvel[i] = X0v[i] + h * sa;
   }
   for (int i = lane; i < nq; i += G) qpos[i] = X0q[i];
@@ -1390,6 +1387,7 @@ MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, c
   int badqpos = 0, badqvel = 0, badqacc = 0;
   gsync<G>();
   const int nstep = a.mode == 1 ? 1 : a.nstep;
+  const int nstage = (a.mode == 0 && m.integrator == INT_RK4) ? 4 : 1;
   for (int s = 0; s < nstep; s++) {
     if (a.mode == 0) {
       if (group_bad<T, G>(w + L.qpos, nq, lane)) { badqpos++; reset_state<T, G>(c); time = 0; }
@@ -1399,10 +1397,18 @@ MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, c
         gsync<G>();
       }
     }
-    forward<T, G>(c);
+    bool retried = false;
+    for (int st = 0; st < nstage; st++) {
+      forward<T, G>(c);                                   // the only call site of the forward pipeline
+      if (a.mode == 1) break;
+      if (st == 0 && !retried && group_bad<T, G>(w + L.qacc, nv, lane)) {
+        badqacc++; reset_state<T, G>(c); time = 0; retried = true; st = -1;
+        continue;
+      }
+      if (nstage == 4) rk4_stage<T, G>(c, st);
+    }
     if (a.mode == 1) break;
-    if (group_bad<T, G>(w + L.qacc, nv, lane)) { badqacc++; reset_state<T, G>(c); time = 0; forward<T, G>(c); }
-    if (m.integrator == INT_RK4) rk4<T, G>(c); else euler<T, G>(c);
+    if (nstage == 1) euler<T, G>(c);
     time += (double)m.timestep;
     if (a.obs_every > 0 && ((s + 1) % a.obs_every) == 0) {
       size_t slot = (size_t)((s + 1) / a.obs_every - 1);
@@ -1433,6 +1439,27 @@ MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, c
     for (int i = lane; i < 4 * m.nbody; i += G) d.xquat[(size_t)env * 4 * m.nbody + i] = (TS)w[L.xquat + i];
     for (int i = lane; i < 3 * m.nsite; i += G) d.site_xpos[(size_t)env * 3 * m.nsite + i] = (TS)w[L.site_xpos + i];
     for (int i = lane; i < 3 * m.ngeom; i += G) d.geom_xpos[(size_t)env * 3 * m.ngeom + i] = (TS)w[L.geom_xpos + i];
+    // A12 sensors of the position/velocity stages (accelerometer needs the post-constraint cacc pass: not built yet -> 0)
+    for (int s = lane; s < m.nsensor; s += G) {
+      TS* out = d.sensordata + (size_t)env * m.nsensordata + m.sensor_adr[s];
+      int id = m.sensor_objid[s], st = m.sensor_type[s];
+      if (st == SENS_JOINTPOS) out[0] = (TS)w[L.qpos + m.jnt_qposadr[id]];
+      else if (st == SENS_GYRO) {
+        int b = m.site_bodyid[id];
+        T R[9], wv[3] = {w[L.cvel + 6 * b], w[L.cvel + 6 * b + 1], w[L.cvel + 6 * b + 2]}, o3[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = w[L.site_xmat + 9 * id + k];
+        mulmatTvec3(o3, R, wv);
+        out[0] = (TS)o3[0]; out[1] = (TS)o3[1]; out[2] = (TS)o3[2];
+      } else if (st == SENS_FRAMEQUAT) {
+        int b = m.site_bodyid[id];
+        T bq[4] = {w[L.xquat + 4 * b], w[L.xquat + 4 * b + 1], w[L.xquat + 4 * b + 2], w[L.xquat + 4 * b + 3]};
+        T sq[4] = {m.site_quat[4 * id], m.site_quat[4 * id + 1], m.site_quat[4 * id + 2], m.site_quat[4 * id + 3]}, q[4];
+        quat_mul(q, bq, sq);
+        quat_normalize(q);
+        out[0] = (TS)q[0]; out[1] = (TS)q[1]; out[2] = (TS)q[2]; out[3] = (TS)q[3];
+      } else { out[0] = 0; out[1] = 0; out[2] = 0; }
+    }
   }
   // optional per-phase dumps (forward mode, parity tests)
   if (dbg.qM) for (int i = lane; i < nv * nv; i += G) dbg.qM[(size_t)env * nv * nv + i] = (TS)w[L.M + i];

@@ -48,7 +48,7 @@ struct HostModel {
   double timestep = 0, gravity[3] = {0, 0, 0}, density = 0, viscosity = 0, tolerance = 1e-8, meaninertia = 1;
   std::vector<std::pair<std::string, std::vector<double>>> fd;
   std::vector<std::pair<std::string, std::vector<int>>> id;
-  std::vector<int> level_adr, level_body, child_adr, child_id;
+  std::vector<int> level_adr, level_body, child_adr, child_id, tri_tab;
   std::vector<unsigned long long> body_dofmask, dof_ancmask;
 
   const std::vector<double>& D(const char* k) const {
@@ -130,6 +130,8 @@ struct HostModel {
     }
     dof_ancmask.assign(nv > 0 ? nv : 1, 0ull);
     for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = dofpar[j]) dof_ancmask[i] |= 1ull << j;
+    tri_tab.clear();
+    for (int r = 0; r < (nv > 0 ? nv : 1); r++) for (int cc = 0; cc <= r; cc++) tri_tab.push_back((r << 16) | cc);
     has_damping = 0;
     for (double v : D("dof_damping")) if (v > 0) has_damping = 1;
     has_fluid = (density > 0 || viscosity > 0) ? 1 : 0;
@@ -169,7 +171,7 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   auto Iq = [&](const char* k) -> const int* { return alloc.puti(h.I(k)); };
   m.body_parentid = Iq("body_parentid"); m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
   m.body_dofadr = Iq("body_dofadr"); m.body_dofnum = Iq("body_dofnum");
-  m.level_adr = alloc.puti(h.level_adr); m.level_body = alloc.puti(h.level_body); m.child_adr = alloc.puti(h.child_adr); m.child_id = alloc.puti(h.child_id);
+  m.level_adr = alloc.puti(h.level_adr); m.level_body = alloc.puti(h.level_body); m.child_adr = alloc.puti(h.child_adr); m.child_id = alloc.puti(h.child_id); m.tri_tab = alloc.puti(h.tri_tab);
   m.body_pos = F("body_pos"); m.body_quat = F("body_quat"); m.body_ipos = F("body_ipos"); m.body_iquat = F("body_iquat"); m.body_mass = F("body_mass");
   m.body_inertia = F("body_inertia"); m.body_subtreemass = F("body_subtreemass"); m.body_invweight0 = F("body_invweight0");
   m.body_dofmask = alloc.putu(h.body_dofmask); m.dof_ancmask = alloc.putu(h.dof_ancmask);
@@ -210,7 +212,7 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   L.efc_J = A(nefc_max * nv); L.efc_pos = A(nefc_max); L.efc_D = A(nefc_max); L.efc_aref = A(nefc_max); L.efc_jar = A(nefc_max);
   L.efc_jv = A(nefc_max); L.efc_force = A(nefc_max); L.efc_KBI = A(nefc_max);
   L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.tmp = A(nv);
-  L.rk = A(h.integrator == INT_RK4 ? nq + nv + 8 * nv + 2 * nv : 0);
+  L.rk = A(h.integrator == INT_RK4 ? nq + nv + 8 * nv + nv : 0);
   L.nT = o;
   int oi = 0;
   auto AI = [&](int n) { int r = oi; oi += n > 0 ? n : 0; return r; };

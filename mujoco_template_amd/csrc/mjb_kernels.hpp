@@ -10,7 +10,7 @@
 namespace mjb {
 
 template <typename T, typename TS, int G>
-__global__ __launch_bounds__(64) void k_step(DevModel<T> m, Lay L, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
+__global__ __launch_bounds__(64, 2) void k_step(DevModel<T> m, Lay L, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
   extern __shared__ __align__(16) char smem[];
   const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
   const int env = blockIdx.x * (64 / G) + sub;
@@ -63,8 +63,12 @@ __global__ __launch_bounds__(64) void k_fd(DevModel<T> m, Lay L, DevData<TS> d, 
     }
     gsync<G>();
   }
-  forward<T, G>(c);
-  if (m.integrator == INT_RK4) rk4<T, G>(c); else euler<T, G>(c);
+  const int nstage = m.integrator == INT_RK4 ? 4 : 1;
+  for (int st = 0; st < nstage; st++) {
+    forward<T, G>(c);
+    if (nstage == 4) rk4_stage<T, G>(c, st);
+  }
+  if (nstage == 1) euler<T, G>(c);
   T* y = y_out + (size_t)gid * (nq + nv);
   for (int i = lane; i < nq; i += G) y[i] = w[L.qpos + i];
   for (int i = lane; i < nv; i += G) y[nq + i] = w[L.qvel + i];

@@ -29,7 +29,7 @@ struct DevModel {
   T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
   // kinematic tree
   const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
-  const int *level_adr, *level_body, *child_adr, *child_id;
+  const int *level_adr, *level_body, *child_adr, *child_id, *tri_tab;
   const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_subtreemass, *body_invweight0;
   const unsigned long long *body_dofmask, *dof_ancmask;
   // joints / dofs

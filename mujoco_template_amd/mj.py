@@ -1,0 +1,390 @@
+"""``mj`` — the slice of the third-party ``mujoco`` Python surface that the reference's
+hot path uses (stub: reference ``mujoco_template/mujoco.pyi:1-75``), re-implemented as a
+thin front of the batched MI355X engine (C ABI ``include/mjbatch.h``).
+
+``MjModel`` wraps a model compiled by :mod:`mujoco_template_amd.mjcf`; ``MjData`` owns
+``batch`` replicas resident on one GPU.  With ``batch == 1`` attribute shapes are those of
+real MuJoCo (``data.qpos.shape == (nq,)``); with ``batch > 1`` every array gains a leading
+batch axis.  Host arrays are float64 *mirrors* of the device state:
+
+* reading an attribute pulls it from the device if the device copy is newer and always
+  returns the same numpy object (so ``np.shares_memory(obs["qpos"], data.qpos)`` holds, as the
+  reference's zero-copy test requires, tests/test_mujoco_template.py:241-252);
+* in-place edits of a mirror (``data.qpos[:] = ...``, as reference controllers do in
+  ``prepare``) are detected against a shadow copy and pushed before the next device call.
+
+There is no CPU physics here: every ``mj_*`` call below launches HIP kernels.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import numpy as np
+
+from . import mjcf
+from ._capi import BatchSim, DeviceModel
+from .exceptions import ConfigError, LinearizationError
+from .mjcf import CompiledModel
+
+# ----------------------------------------------------------------------------------
+# enums
+# ----------------------------------------------------------------------------------
+
+
+class mjtObj:
+    mjOBJ_UNKNOWN = 0
+    mjOBJ_BODY = mjcf.OBJ_BODY
+    mjOBJ_XBODY = mjcf.OBJ_XBODY
+    mjOBJ_JOINT = mjcf.OBJ_JOINT
+    mjOBJ_DOF = mjcf.OBJ_DOF
+    mjOBJ_GEOM = mjcf.OBJ_GEOM
+    mjOBJ_SITE = mjcf.OBJ_SITE
+    mjOBJ_TENDON = mjcf.OBJ_TENDON
+    mjOBJ_ACTUATOR = mjcf.OBJ_ACTUATOR
+    mjOBJ_SENSOR = mjcf.OBJ_SENSOR
+    mjOBJ_KEY = mjcf.OBJ_KEY
+
+
+class mjtJoint:
+    mjJNT_FREE = mjcf.JNT_FREE
+    mjJNT_BALL = mjcf.JNT_BALL
+    mjJNT_SLIDE = mjcf.JNT_SLIDE
+    mjJNT_HINGE = mjcf.JNT_HINGE
+
+
+class FatalError(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------------
+# model
+# ----------------------------------------------------------------------------------
+
+
+class _Option:
+    def __init__(self, model: "MjModel"):
+        object.__setattr__(self, "_model", model)
+
+    @property
+    def timestep(self) -> float:
+        return float(self._model._c.timestep)
+
+    @property
+    def gravity(self) -> np.ndarray:
+        return self._model._c.gravity
+
+    @property
+    def disableactuator(self) -> int:
+        return int(self._model._c.disableactuator)
+
+    @disableactuator.setter
+    def disableactuator(self, mask: int) -> None:
+        self._model._c.disableactuator = int(mask)
+        self._model._device_model().set_disableactuator(int(mask))
+
+    @property
+    def iterations(self) -> int:
+        return int(self._model._c.iterations)
+
+    @property
+    def tolerance(self) -> float:
+        return float(self._model._c.tolerance)
+
+    def __setattr__(self, key: str, value: Any) -> None:
+        if key == "disableactuator":
+            type(self).disableactuator.fset(self, value)  # type: ignore[attr-defined]
+        elif key in ("iterations", "tolerance"):
+            setattr(self._model._c, key, value)
+            self._model._device_model().set_solver(int(self._model._c.iterations), float(self._model._c.tolerance))
+        else:
+            raise AttributeError(f"opt.{key} is read-only in the batched engine (timestep is baked into the device model)")
+
+
+class MjModel:
+    """Compiled model (immutable except ``opt.disableactuator`` / solver knobs)."""
+
+    def __init__(self, compiled: CompiledModel):
+        self._c = compiled
+        self._dm: DeviceModel | None = None
+        self.opt = _Option(self)
+
+    # construction ---------------------------------------------------------------
+    @classmethod
+    def from_xml_path(cls, xml_path: str) -> "MjModel":
+        return cls(mjcf.compile_xml_path(xml_path))
+
+    @classmethod
+    def from_xml_string(cls, xml_text: str) -> "MjModel":
+        return cls(mjcf.compile_xml_string(xml_text))
+
+    def _device_model(self) -> DeviceModel:
+        if self._dm is None:
+            self._dm = DeviceModel(self._c)
+        return self._dm
+
+    # sizes / tables ---------------------------------------------------------------
+    def __getattr__(self, name: str) -> Any:
+        c = self.__dict__.get("_c")
+        if c is None:
+            raise AttributeError(name)
+        if name in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nsensor", "nsensordata", "nkey"):
+            return int(getattr(c, name))
+        if name in c.arrays:
+            arr = c.arrays[name]
+            per = {"actuator_ctrlrange": 2, "actuator_forcerange": 2, "actuator_actrange": 2, "jnt_range": 2}
+            return arr.reshape(-1, per[name]) if name in per else arr
+        raise AttributeError(name)
+
+    @property
+    def compiled(self) -> CompiledModel:
+        return self._c
+
+
+# ----------------------------------------------------------------------------------
+# data
+# ----------------------------------------------------------------------------------
+
+_STATE = ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart")       # writable, pushed when edited
+_DERIVED = ("xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "subtree_com", "sensordata")  # read-only outputs
+_SHAPE3 = {"xpos": 3, "xquat": 4, "xipos": 3, "site_xpos": 3, "geom_xpos": 3, "subtree_com": 3}
+
+
+class MjData:
+    def __init__(self, model: MjModel, batch: int = 1, *, dtype: str = "float32", device: int = 0, lanes: int = 0,
+                 nconmax: int = 0, nefcmax: int = 0, env0: int = 0):
+        if not isinstance(model, MjModel):
+            raise TypeError("MjData(model): model must be an MjModel")
+        if batch < 1:
+            raise ConfigError("batch must be >= 1")
+        self.model = model
+        self.batch = int(batch)
+        self._sim = BatchSim(model._device_model(), self.batch, dtype=dtype, lanes=lanes, nconmax=nconmax, nefcmax=nefcmax,
+                             device=device, env0=env0)
+        self._mirror: dict[str, np.ndarray] = {}
+        self._shadow: dict[str, np.ndarray] = {}
+        self._dev_newer: set[str] = set(_STATE) | set(_DERIVED) | {"time"}
+        self._time = np.zeros(self.batch)
+        self.act = np.zeros(0) if self.batch == 1 else np.zeros((self.batch, 0))
+        c = model._c
+        for name in _STATE + _DERIVED:
+            _, n, _ = self._sim.array_ptr(name)
+            if name in _SHAPE3:
+                shape = (self.batch, n // _SHAPE3[name], _SHAPE3[name])
+            else:
+                shape = (self.batch, n)
+            self._mirror[name] = np.zeros(shape)
+        self._views = {k: (v[0] if self.batch == 1 else v) for k, v in self._mirror.items()}
+        del c
+
+    # -- mirror protocol ---------------------------------------------------------
+    @property
+    def sim(self) -> BatchSim:
+        return self._sim
+
+    def _pull(self, name: str) -> None:
+        if name in self._dev_newer:
+            if name == "time":
+                self._time[:] = self._sim.get("time")[:, 0]
+            else:
+                m = self._mirror[name]
+                m[...] = self._sim.get(name).reshape(m.shape)
+                if name in _STATE:
+                    self._shadow[name] = m.copy()
+            self._dev_newer.discard(name)
+
+    def push_host_edits(self) -> None:
+        """Upload mirrors the user edited in place since they were last pulled."""
+        for name in _STATE:
+            if name in self._dev_newer or name not in self._shadow:
+                continue
+            m = self._mirror[name]
+            if not np.array_equal(m, self._shadow[name]):
+                self._sim.set(name, m.reshape(self.batch, -1))
+                self._shadow[name] = m.copy()
+
+    def mark_device_newer(self, eager: bool = False) -> None:
+        self._dev_newer = set(_STATE) | set(_DERIVED) | {"time"}
+        if eager:
+            self.sync_host()
+
+    def sync_host(self) -> None:
+        for name in _STATE + ("time",):
+            self._pull(name)
+
+    def __getattr__(self, name: str) -> Any:
+        views = self.__dict__.get("_views")
+        if views is not None and name in views:
+            self._pull(name)
+            return views[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        if name in _STATE and "_views" in self.__dict__:
+            self._pull(name)
+            self._views[name][...] = value
+            return
+        object.__setattr__(self, name, value)
+
+    @property
+    def time(self):
+        self._pull("time")
+        return float(self._time[0]) if self.batch == 1 else self._time
+
+    @time.setter
+    def time(self, value) -> None:
+        self._pull("time")
+        self._time[...] = value
+        self._sim.set("time", self._time.reshape(self.batch, 1))
+
+    def counters(self) -> dict[str, np.ndarray]:
+        """Per-environment diagnostics: ncon, nefc, solver_niter, dropped contacts/rows, bad-state resets."""
+        return self._sim.counters()
+
+
+# ----------------------------------------------------------------------------------
+# functions
+# ----------------------------------------------------------------------------------
+
+def _names(model: MjModel) -> CompiledModel:
+    return model._c
+
+
+def mj_name2id(model: MjModel, objtype: int, name: str) -> int:
+    return int(_names(model).name2id(int(objtype), name))
+
+
+def mj_id2name(model: MjModel, objtype: int, idx: int) -> str | None:
+    return _names(model).id2name(int(objtype), int(idx))
+
+
+def _check(model: MjModel, data: MjData) -> None:
+    if data.model is not model:
+        raise FatalError("data was created for a different model")
+
+
+def mj_forward(model: MjModel, data: MjData) -> None:
+    _check(model, data)
+    data.push_host_edits()
+    data._sim.forward()
+    data.mark_device_newer(eager=True)
+
+
+def mj_step(model: MjModel, data: MjData, nstep: int = 1) -> None:
+    _check(model, data)
+    data.push_host_edits()
+    data._sim.step(int(nstep))
+    data.mark_device_newer(eager=True)
+
+
+def mj_resetData(model: MjModel, data: MjData) -> None:
+    _check(model, data)
+    data._sim.reset(-1)
+    data.mark_device_newer(eager=True)
+
+
+def mj_resetDataKeyframe(model: MjModel, data: MjData, key: int) -> None:
+    _check(model, data)
+    data._sim.reset(int(key))
+    data.mark_device_newer(eager=True)
+
+
+def mj_subtreeCoM(model: MjModel, data: MjData) -> None:
+    """subtree_com is produced by every forward pass; nothing further to compute."""
+    _check(model, data)
+
+
+def mjd_transitionFD(model: MjModel, data: MjData, eps: float, centered: bool, A, B, C=None, D=None, *unsupported) -> None:
+    """Batched finite-difference transition matrices (float64 on device)."""
+    if unsupported:
+        raise TypeError("mjd_transitionFD takes 8 positional arguments")
+    _check(model, data)
+    data.push_host_edits()
+    Ab, Bb = data._sim.transition_fd(float(eps), bool(centered))
+    if A is not None:
+        A[...] = Ab[0] if A.ndim == 2 else Ab
+    if B is not None and model.nu > 0:
+        B[...] = Bb[0] if B.ndim == 2 else Bb
+
+
+def _jac(model: MjModel, data: MjData, kind: int, idx: int, jacp, jacr) -> None:
+    _check(model, data)
+    data.push_host_edits()
+    jp, jr = data._sim.jac([kind], [int(idx)])
+    if jacp is not None:
+        jacp[...] = jp[0, 0] if jacp.ndim == 2 else jp[:, 0]
+    if jacr is not None:
+        jacr[...] = jr[0, 0] if jacr.ndim == 2 else jr[:, 0]
+
+
+def mj_jacSite(model, data, jacp, jacr, site_id) -> None:
+    _jac(model, data, 0, site_id, jacp, jacr)
+
+
+def mj_jacBody(model, data, jacp, jacr, body_id) -> None:
+    _jac(model, data, 1, body_id, jacp, jacr)
+
+
+def mj_jacBodyCom(model, data, jacp, jacr, body_id) -> None:
+    _jac(model, data, 2, body_id, jacp, jacr)
+
+
+def mj_jacSubtreeCom(model, data, jacp, body_id) -> None:
+    _jac(model, data, 3, body_id, jacp, None)
+
+
+# position manifold helpers run on the host: they act on caller-owned numpy vectors
+# (controllers call them every step, reference examples/humanoid/controllers/lqr.py:153)
+
+def _quat_mul(a, b):
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0],
+    ])
+
+
+def mj_integratePos(model: MjModel, qpos: np.ndarray, qvel: np.ndarray, dt: float) -> None:
+    c = model._c
+    for j in range(c.njnt):
+        qa, da = int(c.jnt_qposadr[j]), int(c.jnt_dofadr[j])
+        if c.jnt_type[j] == mjcf.JNT_FREE:
+            qpos[qa:qa + 3] += dt * qvel[da:da + 3]
+            w = np.asarray(qvel[da + 3:da + 6], dtype=float)
+            n = float(np.linalg.norm(w))
+            if n > 1e-15:
+                ang = dt * n
+                qr = np.concatenate([[math.cos(ang / 2)], w / n * math.sin(ang / 2)])
+                q = _quat_mul(qpos[qa + 3:qa + 7], qr)
+                qpos[qa + 3:qa + 7] = q / np.linalg.norm(q)
+        else:
+            qpos[qa] += dt * qvel[da]
+
+
+def mj_differentiatePos(model: MjModel, qvel: np.ndarray, dt: float, qpos1: np.ndarray, qpos2: np.ndarray) -> None:
+    c = model._c
+    for j in range(c.njnt):
+        qa, da = int(c.jnt_qposadr[j]), int(c.jnt_dofadr[j])
+        if c.jnt_type[j] == mjcf.JNT_FREE:
+            qvel[da:da + 3] = (qpos2[qa:qa + 3] - qpos1[qa:qa + 3]) / dt
+            q1 = np.asarray(qpos1[qa + 3:qa + 7], dtype=float)
+            qd = _quat_mul(np.array([q1[0], -q1[1], -q1[2], -q1[3]]), np.asarray(qpos2[qa + 3:qa + 7], dtype=float))
+            s = float(np.linalg.norm(qd[1:]))
+            if s < 1e-15:
+                qvel[da + 3:da + 6] = 0.0
+            else:
+                ang = 2 * math.atan2(s, qd[0])
+                if ang > math.pi:
+                    ang -= 2 * math.pi
+                qvel[da + 3:da + 6] = qd[1:] / s * ang / dt
+        else:
+            qvel[da] = (qpos2[qa] - qpos1[qa]) / dt
+
+
+__all__ = [
+    "MjModel", "MjData", "mjtObj", "mjtJoint", "FatalError", "mj_name2id", "mj_id2name", "mj_forward", "mj_step",
+    "mj_resetData", "mj_resetDataKeyframe", "mj_subtreeCoM", "mjd_transitionFD", "mj_jacSite", "mj_jacBody",
+    "mj_jacBodyCom", "mj_jacSubtreeCom", "mj_integratePos", "mj_differentiatePos",
+]

@@ -893,9 +893,9 @@ class _Compiler:
                     raise MjcfError(f"keyframe {e.get('name')!r}: size mismatch (qpos {qpos.size} vs nq {m.nq})")
                 keys.append(dict(name=e.get("name", ""), qpos=qpos, qvel=qvel, ctrl=ctrl, time=float(e.get("time", 0))))
         m.nkey = len(keys)
-        A["key_qpos"] = np.array([k["qpos"] for k in keys]).reshape(-1, m.nq)
-        A["key_qvel"] = np.array([k["qvel"] for k in keys]).reshape(-1, m.nv)
-        A["key_ctrl"] = np.array([k["ctrl"] for k in keys]).reshape(-1, m.nu)
+        A["key_qpos"] = np.array([k["qpos"] for k in keys], dtype=np.float64).reshape(len(keys), m.nq)
+        A["key_qvel"] = np.array([k["qvel"] for k in keys], dtype=np.float64).reshape(len(keys), m.nv)
+        A["key_ctrl"] = np.array([k["ctrl"] for k in keys], dtype=np.float64).reshape(len(keys), m.nu)
         A["key_time"] = np.array([k["time"] for k in keys], dtype=np.float64)
         m.names[OBJ_KEY] = [k["name"] for k in keys]
 

@@ -1,0 +1,90 @@
+"""Passive rollout loop (reference ``mujoco_template/runtime.py:620-685``):
+``iterate_passive`` / ``run_passive_headless`` keep their signatures.  When the environment's
+controller runs on the device and no per-step Python hook is attached, ``run_passive_headless``
+executes the whole loop as fused K-step kernel launches (one host crossing per chunk for the
+whole batch instead of one per step per environment).
+"""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Iterable, Iterator
+from typing import TYPE_CHECKING
+
+import numpy as np
+
+from .exceptions import ConfigError
+
+if TYPE_CHECKING:  # pragma: no cover
+    from .env import Env, StepResult
+
+StepHook = Callable[["StepResult"], None]
+
+
+def _normalize_hooks(hooks: StepHook | Iterable[StepHook] | None) -> tuple[StepHook, ...]:
+    if hooks is None:
+        return ()
+    if callable(hooks):
+        return (hooks,)
+    normalized = tuple(hooks)
+    if not all(callable(h) for h in normalized):
+        raise ConfigError("All hooks must be callables accepting StepResult.")
+    return normalized
+
+
+def _validate(duration: float | None, max_steps: int | None) -> None:
+    if duration is not None and duration < 0:
+        raise ConfigError("duration must be >= 0 when provided.")
+    if max_steps is not None and max_steps < 1:
+        raise ConfigError("max_steps must be >= 1 when provided.")
+
+
+def _time_reached(env: "Env", duration: float) -> bool:
+    return bool(np.all(np.asarray(env.data.time) >= duration))
+
+
+def iterate_passive(env: "Env", *, duration: float | None = None, max_steps: int | None = None,
+                    hooks: StepHook | Iterable[StepHook] | None = None, return_obs: bool = True) -> Iterator["StepResult"]:
+    """Yield one ``StepResult`` per step; the stop condition is checked after the step (>= 1 step always)."""
+    _validate(duration, max_steps)
+    active_hooks = _normalize_hooks(hooks)
+    steps = 0
+    while True:
+        result = env.step(return_obs=return_obs)
+        steps += 1
+        for hook in active_hooks:
+            hook(result)
+        yield result
+        if max_steps is not None and steps >= max_steps:
+            break
+        if duration is not None and _time_reached(env, duration):
+            break
+
+
+def run_passive_headless(env: "Env", *, duration: float | None = None, max_steps: int | None = None,
+                         hooks: StepHook | Iterable[StepHook] | None = None, return_obs: bool = True,
+                         chunk: int = 256) -> int:
+    """Drive the environment headlessly and return the executed step count."""
+    _validate(duration, max_steps)
+    active_hooks = _normalize_hooks(hooks)
+    if not active_hooks and env.can_fuse():   # nothing observes the intermediate StepResults
+        # fused path: number of steps is known up front (time advances by exactly one timestep per step)
+        dt = float(env.model.opt.timestep)
+        limit = max_steps
+        if duration is not None:
+            t0 = float(np.min(np.asarray(env.data.time)))
+            need = max(1, int(np.ceil((duration - t0) / dt - 1e-9)))
+            limit = need if limit is None else min(limit, need)
+        if limit is not None:
+            done = 0
+            while done < limit:
+                n = min(chunk, limit - done)
+                env.rollout(n)
+                done += n
+            return done
+    steps = 0
+    for _ in iterate_passive(env, duration=duration, max_steps=max_steps, hooks=active_hooks, return_obs=return_obs):
+        steps += 1
+    return steps
+
+
+__all__ = ["StepHook", "iterate_passive", "run_passive_headless", "_normalize_hooks"]

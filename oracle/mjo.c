@@ -87,6 +87,7 @@ struct mjoData {
   /* solver scratch */
   double *s_Ma, *s_grad, *s_Mgrad, *s_search, *s_Mv, *s_jv, *s_tmp;
   double solver_cost;
+  double* jacbuf;   /* 6*nv scratch for Jacobians */
   int* iscratch;
 };
 
@@ -378,7 +379,7 @@ mjoData* mjo_data_create(const mjoModel* m) {
   d->efc_R = dalloc(ne); d->efc_D = dalloc(ne); d->efc_KBIP = dalloc(ne * 4); d->efc_vel = dalloc(ne); d->efc_aref = dalloc(ne);
   d->efc_force = dalloc(ne); d->efc_jar = dalloc(ne);
   d->s_Ma = dalloc(nv); d->s_grad = dalloc(nv); d->s_Mgrad = dalloc(nv); d->s_search = dalloc(nv); d->s_Mv = dalloc(nv);
-  d->s_jv = dalloc(ne); d->s_tmp = dalloc(nv > ne ? nv : ne);
+  d->s_jv = dalloc(ne); d->s_tmp = dalloc(nv > ne ? nv : ne); d->jacbuf = dalloc(6 * nv);
   mjo_reset(m, d);
   return d;
 }
@@ -391,7 +392,7 @@ void mjo_data_free(mjoData* d) {
     &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->qM, &d->qL, &d->qH, &d->ten_length, &d->ten_J, &d->ten_velocity,
     &d->actuator_length, &d->actuator_velocity, &d->actuator_force, &d->actuator_moment, &d->sensordata, &d->efc_J, &d->efc_pos,
     &d->efc_margin, &d->efc_diagApprox, &d->efc_R, &d->efc_D, &d->efc_KBIP, &d->efc_vel, &d->efc_aref, &d->efc_force, &d->efc_jar,
-    &d->s_Ma, &d->s_grad, &d->s_Mgrad, &d->s_search, &d->s_Mv, &d->s_jv, &d->s_tmp};
+    &d->s_Ma, &d->s_grad, &d->s_Mgrad, &d->s_search, &d->s_Mv, &d->s_jv, &d->s_tmp, &d->jacbuf};
   for (size_t i = 0; i < sizeof(f) / sizeof(f[0]); i++) free(*f[i]);
   free(d->contact); free(d->efc_type); free(d->efc_id); free(d->efc_active);
   free(d);
@@ -584,7 +585,7 @@ static void tendon_transmission(const mjoModel* m, mjoData* d) {
     }
     d->ten_length[t] = len;
   }
-  double* jp = (double*)malloc(sizeof(double) * 6 * (nv > 0 ? nv : 1));
+  double* jp = d->jacbuf;
   double* jr = jp + 3 * nv;
   for (int a = 0; a < m->nu; a++) {
     double* mom = d->actuator_moment + (size_t)a * nv;
@@ -603,7 +604,6 @@ static void tendon_transmission(const mjoModel* m, mjoData* d) {
         mom[i] = jp[i] * f[0] + jp[nv + i] * f[1] + jp[2 * nv + i] * f[2] + jr[i] * tq[0] + jr[nv + i] * tq[1] + jr[2 * nv + i] * tq[2];
     }
   }
-  free(jp);
 }
 
 /* A4  composite rigid body + dense factor (mj_crb, mj_factorM) */
@@ -862,7 +862,7 @@ static void make_constraint(const mjoModel* m, mjoData* d) {
     }
   }
   /* contacts: frictionless (condim 1) or pyramidal (condim 3) */
-  double* jp1 = (double*)malloc(sizeof(double) * 6 * (nv > 0 ? nv : 1));
+  double* jp1 = d->jacbuf;
   double* jp2 = jp1 + 3 * nv;
   int overflow = 0;
   for (int c = 0; c < d->ncon; c++) {
@@ -902,7 +902,6 @@ static void make_constraint(const mjoModel* m, mjoData* d) {
       for (int r = 0; r < rows; r++) d->efc_R[first + r] = Rpy;
     }
   }
-  free(jp1);
   for (int i = 0; i < d->nefc; i++) d->efc_D[i] = 1 / d->efc_R[i];
 }
 
@@ -949,12 +948,11 @@ static void com_vel(const mjoModel* m, mjoData* d) {
 /* apply a force/torque at a world point of `body` to generalized forces (mj_applyFT) */
 static void apply_ft(const mjoModel* m, const mjoData* d, const double* force, const double* torque, const double* point, int body, double* qfrc) {
   int nv = m->nv;
-  double* jp = (double*)malloc(sizeof(double) * 6 * (nv > 0 ? nv : 1));
+  double* jp = d->jacbuf;
   double* jr = jp + 3 * nv;
   jac_point(m, d, body, point, jp, jr);
   for (int i = 0; i < nv; i++)
     qfrc[i] += jp[i] * force[0] + jp[nv + i] * force[1] + jp[2 * nv + i] * force[2] + jr[i] * torque[0] + jr[nv + i] * torque[1] + jr[2 * nv + i] * torque[2];
-  free(jp);
 }
 
 static void passive(const mjoModel* m, mjoData* d) {
@@ -1399,4 +1397,29 @@ void mjo_jac(const mjoModel* m, const mjoData* d, int kind, int id, double* jacp
     if (jacp && m->body_subtreemass[id] > MINVAL) for (int k = 0; k < 3 * nv; k++) jacp[k] /= m->body_subtreemass[id];
     free(tmp);
   }
+}
+
+/* ------------------------------------------------------------------------- */
+/* CPU-baseline helper: nenv independent random-ctrl rollouts, one env per OpenMP task. */
+/* qpos_out (may be NULL): [nenv, nq] final positions.  Returns env-steps executed.      */
+/* ------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+long mjo_rollout_batch(const mjoModel* m, int nenv, int nstep, unsigned seed, unsigned env0, double scale, int nthreads,
+                       const double* qpos_init, const double* qvel_init, double* qpos_out, double* qvel_out) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int e = 0; e < nenv; e++) {
+    mjoData* d = mjo_data_create(m);
+    if (qpos_init) memcpy(d->qpos, qpos_init + (size_t)e * m->nq, sizeof(double) * m->nq);
+    if (qvel_init) memcpy(d->qvel, qvel_init + (size_t)e * m->nv, sizeof(double) * m->nv);
+    mjo_rollout_random(m, d, nstep, seed, env0 + (unsigned)e, 0u, scale);
+    if (qpos_out) memcpy(qpos_out + (size_t)e * m->nq, d->qpos, sizeof(double) * m->nq);
+    if (qvel_out) memcpy(qvel_out + (size_t)e * m->nv, d->qvel, sizeof(double) * m->nv);
+    mjo_data_free(d);
+  }
+  return (long)nenv * nstep;
 }

@@ -61,6 +61,10 @@ void mjo_random_ctrl(const mjoModel* m, double* ctrl, unsigned seed, unsigned en
 void mjo_rollout_random(const mjoModel* m, mjoData* d, int nstep, unsigned seed, unsigned env,
                         unsigned step0, double scale);
 
+/* CPU-baseline helper: nenv independent random-ctrl rollouts across OpenMP threads; returns env-steps executed */
+long mjo_rollout_batch(const mjoModel* m, int nenv, int nstep, unsigned seed, unsigned env0, double scale, int nthreads,
+                       const double* qpos_init, const double* qvel_init, double* qpos_out, double* qvel_out);
+
 void mjo_transition_fd(const mjoModel* m, mjoData* d, double eps, int centered, double* A, double* B);
 /* kind: 0 site, 1 body (frame origin), 2 body com, 3 subtree com.  jacp/jacr may be NULL. */
 void mjo_jac(const mjoModel* m, const mjoData* d, int kind, int id, double* jacp, double* jacr);

@@ -57,6 +57,8 @@ def lib() -> ctypes.CDLL:
         L.mjo_step.argtypes = [vp, vp]
         L.mjo_random_ctrl.argtypes = [vp, vp, cu, cu, cu, cd]
         L.mjo_rollout_random.argtypes = [vp, vp, ci, cu, cu, cu, cd]
+        L.mjo_rollout_batch.restype = ctypes.c_long
+        L.mjo_rollout_batch.argtypes = [vp, ci, ci, cu, cu, cd, ci, vp, vp, vp, vp]
         L.mjo_transition_fd.argtypes = [vp, vp, cd, ci, vp, vp]
         L.mjo_jac.argtypes = [vp, vp, ci, ci, vp, vp]
         L.mjo_integrate_pos.argtypes = [vp, vp, vp, cd]
@@ -95,6 +97,17 @@ class OracleModel:
                 self.ptr = None
         except Exception:
             pass
+
+
+def rollout_batch(model: "OracleModel", nenv: int, nstep: int, seed: int = 0, env0: int = 0, scale: float = 1.0, nthreads: int = 0,
+                  qpos_init=None, qvel_init=None):
+    """nenv independent random-ctrl rollouts (OpenMP, one env per task). Returns (qpos [nenv,nq], qvel [nenv,nv])."""
+    qo = np.zeros((nenv, model.nq)); vo = np.zeros((nenv, model.nv))
+    qi = None if qpos_init is None else np.ascontiguousarray(qpos_init, dtype=np.float64)
+    vi = None if qvel_init is None else np.ascontiguousarray(qvel_init, dtype=np.float64)
+    lib().mjo_rollout_batch(model.ptr, int(nenv), int(nstep), seed, env0, float(scale), int(nthreads),
+                            None if qi is None else qi.ctypes.data, None if vi is None else vi.ctypes.data, qo.ctypes.data, vo.ctypes.data)
+    return qo, vo
 
 
 class OracleData:
@@ -224,4 +237,4 @@ def load(xml_path: str) -> tuple[OracleModel, OracleData]:
     return m, OracleData(m)
 
 
-__all__ = ["OracleModel", "OracleData", "load", "build", "lib"]
+__all__ = ["OracleModel", "OracleData", "load", "build", "lib", "rollout_batch"]

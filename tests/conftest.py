@@ -1,0 +1,76 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODELS = {
+    "pendulum": os.path.join(ROOT, "models", "pendulum.xml"),
+    "cartpole": os.path.join(ROOT, "models", "cartpole.xml"),
+    "humanoid": os.path.join(ROOT, "models", "humanoid.xml"),
+    "drone2": os.path.join(ROOT, "models", "drone2", "scene.xml"),
+}
+
+# the reference's test model (reference tests/test_mujoco_template.py:40-61), reproduced as test data
+BASE_XML = """
+<mujoco model="template-test">
+  <option timestep="0.005"/>
+  <default>
+    <joint limited="true" range="-1 1"/>
+  </default>
+  <worldbody>
+    <body name="torso">
+      <joint name="hinge" type="hinge" axis="0 0 1"/>
+      <geom name="torso_geom" type="capsule" size="0.04 0.2" pos="0 0 0"/>
+      <site name="tip" pos="0 0 0.2"/>
+    </body>
+  </worldbody>
+  <actuator>
+    <motor name="torque_act" joint="hinge" group="0" forcelimited="true" forcerange="-10 10"/>
+    <position name="pos_act" joint="hinge" group="1" ctrllimited="true" ctrlrange="-0.5 0.5"/>
+  </actuator>
+  <sensor>
+    <jointpos name="hinge_pos" joint="hinge"/>
+  </sensor>
+</mujoco>
+"""
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def models():
+    return MODELS
+
+
+@pytest.fixture(scope="session")
+def compiled():
+    from mujoco_template_amd.mjcf import compile_xml_path
+
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = compile_xml_path(MODELS[name])
+        return cache[name]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def oracle(compiled):
+    from oracle import mjo
+
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = mjo.OracleModel(compiled(name))
+        return cache[name], mjo.OracleData(cache[name])
+
+    return get

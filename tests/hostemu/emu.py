@@ -51,6 +51,7 @@ class EmuEnv:
             "qacc": np.zeros(nv), "qacc_warmstart": np.zeros(nv), "time": np.zeros(1), "counters": np.zeros(8, dtype=np.int32),
             "xpos": np.zeros(3 * m.nbody), "xquat": np.zeros(4 * m.nbody), "xipos": np.zeros(3 * m.nbody),
             "site_xpos": np.zeros(max(3 * m.nsite, 1)), "geom_xpos": np.zeros(max(3 * m.ngeom, 1)), "subtree_com": np.zeros(3 * m.nbody),
+            "sensordata": np.zeros(max(m.nsensordata, 1)),
             "qM": np.zeros(nv * nv), "qfrc_bias": np.zeros(nv), "qfrc_passive": np.zeros(nv), "qfrc_actuator": np.zeros(nv),
             "qacc_smooth": np.zeros(nv), "qfrc_constraint": np.zeros(nv),
             "efc_J": np.zeros(self.nefc_max * nv), "efc_aref": np.zeros(self.nefc_max), "efc_D": np.zeros(self.nefc_max),

@@ -1,0 +1,299 @@
+"""The reference's unit/integration assertions (reference tests/test_mujoco_template.py:74-588: shapes,
+key sets, identity / shares_memory, call counts, ordering) re-targeted at the batched ``Env``, plus
+the batched fast paths (fused rollout, device observation gather).  Needs a GPU (no CPU fallback)."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import mujoco_template_amd as mt  # noqa: E402
+from mujoco_template_amd import mj  # noqa: E402
+from mujoco_template_amd import runtime  # noqa: E402
+from tests.conftest import BASE_XML, MODELS  # noqa: E402
+
+
+@pytest.fixture
+def handle():
+    h = mt.ModelHandle.from_xml_string(BASE_XML)
+    h.forward()
+    return h
+
+
+def test_model_handle_wraps_existing_data():
+    model = mj.MjModel.from_xml_string(BASE_XML)
+    data = mj.MjData(model)
+    data.qpos[0] = 0.25
+    h = mt.ModelHandle.from_model_and_data(model, data)
+    assert h.model is model and h.data is data
+    env = mt.Env(h, obs_spec=mt.ObservationSpec(include_qpos=True))
+    assert env.data is data
+    env.reset()
+    assert env.data is data
+
+
+def test_model_handle_rejects_mismatched_data():
+    a, b = mj.MjModel.from_xml_string(BASE_XML), mj.MjModel.from_xml_string(BASE_XML)
+    with pytest.raises(mt.ConfigError):
+        mt.ModelHandle(a, data=mj.MjData(b))
+
+
+def test_host_edits_reach_the_device(handle):
+    handle.data.qpos[0] = 0.3                    # in-place edit of the mirror, as reference controllers do in prepare()
+    handle.forward()
+    assert handle.data.site_xpos[0] == pytest.approx([0, 0, 0.2])
+    assert handle.data.sensordata[0] == pytest.approx(0.3, abs=1e-6)     # jointpos sensor follows the edit
+    handle.data.qvel[:] = 1.0
+    handle.step()
+    assert handle.data.qpos[0] > 0.3
+
+
+def test_env_step_can_skip_observation_and_hooks(handle):
+    calls = {"extract": 0, "reward": 0, "done": 0, "info": 0}
+    seen = []
+
+    def reward_fn(model, data, obs):
+        calls["reward"] += 1; seen.append(obs); return 0.0
+
+    def done_fn(model, data, obs):
+        calls["done"] += 1; seen.append(obs); return False
+
+    def info_fn(model, data, obs):
+        calls["info"] += 1; seen.append(obs); return {"value": float(data.time)}
+
+    env = mt.Env(handle, obs_spec=mt.ObservationSpec(include_qpos=True), reward_fn=reward_fn, done_fn=done_fn, info_fn=info_fn)
+    original = env.extractor
+
+    def counting(data):
+        calls["extract"] += 1
+        return original(data)
+
+    env.extractor = counting
+    env.reset()
+    for k in calls:
+        calls[k] = 0
+    seen.clear()
+    result = env.step(return_obs=False)
+    assert calls == {"extract": 0, "reward": 1, "done": 1, "info": 1}
+    assert seen == [None, None, None]
+    assert result.obs is None and result.reward == 0.0 and result.done is False
+    assert result.info == {"value": pytest.approx(float(env.data.time))}
+
+
+def test_iterate_passive_respects_return_obs_flag(handle):
+    env = mt.Env(handle, obs_spec=mt.ObservationSpec(include_qpos=True))
+    original, n = env.extractor, [0]
+
+    def counting(data):
+        n[0] += 1
+        return original(data)
+
+    env.extractor = counting
+    env.reset()
+    n[0] = 0
+    results = list(runtime.iterate_passive(env, max_steps=2, return_obs=False))
+    assert n[0] == 0 and all(r.obs is None for r in results)
+
+
+def test_observation_extractor_dict_and_array(handle):
+    spec = dict(include_qpos=True, include_qvel=True, include_act=True, include_ctrl=True, include_sensordata=True, include_time=True,
+                sites_pos=("tip",), bodies_pos=("torso",), geoms_pos=("torso_geom",), subtree_com=("torso",))
+    ex = mt.ObservationExtractor(handle.model, mt.ObservationSpec(as_dict=True, **spec))
+    obs = ex(handle.data)
+    assert set(obs) == {"qpos", "qvel", "act", "ctrl", "sensordata", "time", "sites_pos", "bodies_pos", "geoms_pos", "subtree_com"}
+    m = handle.model
+    assert obs["qpos"].shape == (m.nq,) and obs["qvel"].shape == (m.nv,) and obs["ctrl"].shape == (m.nu,)
+    assert obs["sensordata"].shape == (m.nsensordata,) and obs["time"].shape == (1,)
+    assert obs["sites_pos"].shape == (1, 3) and obs["bodies_pos"].shape == (1, 3) and obs["geoms_pos"].shape == (1, 3)
+    flat = mt.ObservationExtractor(m, mt.ObservationSpec(as_dict=False, **spec))(handle.data)
+    assert flat.shape == (m.nq + m.nv + m.nu + m.nsensordata + 1 + 3 + 3 + 3 + 3,)
+    # device gather kernel produces the same flat layout (sorted keys)
+    dev = mt.ObservationExtractor(m, mt.ObservationSpec(as_dict=False, **{**spec, "include_act": False})).gather_device(handle.data)
+    assert dev.shape == (1, flat.size) and dev.cpu().numpy()[0] == pytest.approx(flat, abs=1e-6)
+
+
+def test_observation_extractor_zero_copy_flag(handle):
+    obs = mt.ObservationExtractor(handle.model, mt.ObservationSpec(copy=False))(handle.data)
+    assert np.shares_memory(obs["qpos"], handle.data.qpos) and np.shares_memory(obs["qvel"], handle.data.qvel)
+    obs = mt.ObservationExtractor(handle.model, mt.ObservationSpec(copy=True))(handle.data)
+    assert not np.shares_memory(obs["qpos"], handle.data.qpos)
+
+
+def test_observation_extractor_custom_extras(handle):
+    spec = mt.ObservationSpec(include_qpos=False, include_qvel=False,
+                              extras={"twice": lambda m, d: 2 * np.array(d.qpos), "prod": mt.ObservationProducer(lambda m, d: [1.0, 2.0], copy=True)})
+    obs = mt.ObservationExtractor(handle.model, spec)(handle.data)
+    assert set(obs) == {"twice", "prod"} and obs["prod"].tolist() == [1.0, 2.0]
+    with pytest.raises(ValueError):
+        mt.ObservationExtractor(handle.model, mt.ObservationSpec(extras={"qpos": lambda m, d: [0.0]}))(handle.data)
+    with pytest.raises(TypeError):
+        mt.ObservationExtractor(handle.model, mt.ObservationSpec(extras={"bad": 3}))
+
+
+def test_observation_extractor_missing_sensors_warns_once():
+    h = mt.ModelHandle.from_xml_path(MODELS["cartpole"])
+    ex = mt.ObservationExtractor(h.model, mt.ObservationSpec(include_sensordata=True))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        a = ex(h.data); ex(h.data)
+    assert a["sensordata"].shape == (0,)
+    assert len([x for x in w if issubclass(x.category, RuntimeWarning)]) == 1
+
+
+def test_model_handle_actuator_group_mask(handle):
+    handle.set_enabled_actuator_groups([1])
+    assert int(handle.model.opt.disableactuator) == 1 << 0
+    assert handle.enabled_actuator_mask().tolist() == [False, True]
+    # the disabled torque motor produces no force on the device
+    handle.data.ctrl[:] = [5.0, 0.0]
+    handle.forward()
+    assert abs(handle.data.qacc[0]) < 1e-6
+    with pytest.raises(mt.CompatibilityError):
+        handle.set_enabled_actuator_groups([])
+    with pytest.raises(mt.ConfigError):
+        handle.set_enabled_actuator_groups([40])
+    with pytest.raises(mt.CompatibilityError):
+        handle.set_enabled_actuator_groups([7])
+
+
+def test_linearize_discrete_native_and_fd(handle):
+    for native in (True, False):
+        A, B = mt.linearize_discrete(handle.model, handle.data, use_native=native)
+        assert A.shape == (2, 2) and B.shape == (2, 2)
+        assert np.isfinite(A).all() and np.isfinite(B).all()
+    A1, B1 = mt.linearize_discrete(handle.model, handle.data, use_native=True)
+    A2, B2 = mt.linearize_discrete(handle.model, handle.data, use_native=False)
+    assert A1 == pytest.approx(A2, abs=1e-4) and B1 == pytest.approx(B2, abs=1e-4)      # both use the native sign convention
+
+
+def test_compute_requested_jacobians_returns_expected_blocks(handle):
+    jac = mt.compute_requested_jacobians(handle.model, handle.data, ["site:tip", "body:torso", "bodycom:torso", "subtreecom:torso"])
+    nv = handle.model.nv
+    assert set(jac) == {"site:tip", "body:torso", "bodycom:torso", "subtreecom:torso"}
+    assert jac["site:tip"]["jacp"].shape == (3, nv) and jac["site:tip"]["jacr"].shape == (3, nv)
+    assert set(jac["bodycom:torso"]) == {"jacp"} and set(jac["subtreecom:torso"]) == {"jacp"}
+    assert jac["site:tip"]["jacr"][:, 0] == pytest.approx([0, 0, 1])          # hinge about z
+    with pytest.raises(mt.ConfigError):
+        mt.compute_requested_jacobians(handle.model, handle.data, ["com"])
+    with pytest.raises(mt.NameLookupError):
+        mt.compute_requested_jacobians(handle.model, handle.data, ["site:nope"])
+
+
+class _Ctl:
+    def __init__(self, caps):
+        self.capabilities = caps
+        self.prepared = 0
+        self.calls = []
+
+    def prepare(self, model, data):
+        self.prepared += 1
+
+    def __call__(self, model, data, t):
+        self.calls.append((t, float(data.qpos[0])))
+        data.ctrl[:] = [0.5, 0.1]
+
+
+def test_env_step_invokes_controller_and_produces_precomputes(handle):
+    caps = mt.ControllerCapabilities(control_space=mt.ControlSpace.TORQUE, needs_linearization=True,
+                                     needs_jacobians=("site:tip", "bodycom:torso"), actuator_groups=(0,))
+    ctl = _Ctl(caps)
+    with pytest.warns(RuntimeWarning):
+        env = mt.Env(handle, obs_spec=mt.ObservationSpec(include_ctrl=True), controller=ctl, control_decimation=2,
+                     info_fn=lambda m, d, o: {"extra_metric": 1.0})
+    env.reset()
+    assert ctl.prepared == 2                                      # __init__ and reset (reference tests:452-454)
+    r1 = env.step()
+    assert len(ctl.calls) == 1 and ctl.calls[0][0] == pytest.approx(0.0)
+    assert r1.info["A"].shape == (2, 2) and r1.info["B"].shape == (2, 2)
+    assert set(r1.info["jacobians"]) == {"site:tip", "bodycom:torso"}
+    assert "compat_warnings" in r1.info and r1.info["extra_metric"] == 1.0
+    assert r1.obs["ctrl"] == pytest.approx([0.5, 0.1], abs=1e-6)
+    r2 = env.step()
+    assert len(ctl.calls) == 1                                    # decimation 2: no controller call on the odd substep
+    assert "A" not in r2.info and "compat_warnings" not in r2.info
+    env.step()
+    assert len(ctl.calls) == 2 and ctl.calls[1][0] == pytest.approx(2 * 0.005)
+    env2 = mt.Env(handle, info_fn=lambda m, d, o: {"compat_warnings": 1}, controller=_Ctl(mt.ControllerCapabilities()))
+    with pytest.raises(mt.TemplateError):
+        env2.step()
+
+
+def test_env_step_accumulates_substep_instrumentation(handle):
+    caps = mt.ControllerCapabilities(needs_linearization=True, needs_jacobians=("site:tip",))
+    env = mt.Env(handle, controller=_Ctl(caps))
+    env.reset()
+    r = env.step(3)
+    assert isinstance(r.info["A"], list) and len(r.info["A"]) == 3 and len(r.info["B"]) == 3 and len(r.info["jacobians"]) == 3
+    with pytest.raises(mt.ConfigError):
+        env.step(0)
+    with pytest.raises(mt.ConfigError):
+        mt.Env(handle, control_decimation=0)
+
+
+def test_env_from_xml_path_auto_resets_and_pendulum_config1():
+    """BASELINE config 1: examples/pendulum, ZeroController, Env.passive 200 steps, batch 1."""
+    env = mt.Env.from_xml_path(MODELS["pendulum"], controller=mt.ZeroController())
+    assert env.data.time == pytest.approx(0.0)
+    env.data.qpos[0] = np.pi / 2                                   # released from 90 degrees (pendulum_passive_config.py:58)
+    results = list(env.passive(max_steps=200))
+    assert len(results) == 200 and all(isinstance(r, mt.StepResult) for r in results)
+    assert env.data.time == pytest.approx(200 * 0.005)
+    assert set(results[-1].obs) == {"qpos", "qvel"}
+    m, I, L = 0.7941946228, 0.06809102997, 0.25
+    energy = 0.5 * I * env.data.qvel[0] ** 2 - m * 9.81 * L * np.cos(env.data.qpos[0])
+    assert energy == pytest.approx(0.0, abs=2e-4)                  # RK4 in fp32: energy of the 90-degree release is conserved
+    with pytest.raises(mt.ConfigError):
+        mt.Env.from_xml_path(MODELS["pendulum"], auto_reset=False, keyframe=0)
+    with pytest.raises(mt.ConfigError):
+        list(env.passive(max_steps=0))
+    with pytest.raises(mt.ConfigError):
+        list(env.passive(duration=-1.0))
+
+
+def test_env_passive_duration_and_keyframes():
+    env = mt.Env.from_xml_path(MODELS["drone2"], keyframe="hover")
+    assert env.data.qpos == pytest.approx([0, 0, 0.3, 1, 0, 0, 0]) and env.data.ctrl == pytest.approx([3.2495625] * 4)
+    n = runtime.run_passive_headless(env, duration=0.1)
+    assert n == 10 and env.data.time == pytest.approx(0.1)
+    assert env.data.qpos == pytest.approx([0, 0, 0.3, 1, 0, 0, 0], abs=1e-5)    # hover is a fixed point (K1)
+    with pytest.raises(mt.NameLookupError):
+        env.reset("nope")
+    with pytest.raises(mt.ConfigError):
+        env.reset(5)
+
+
+def test_batched_env_fused_rollout_matches_stepwise():
+    """The fused K-step kernel launch and the per-step Env.step loop produce identical states (same RNG stream)."""
+    kw = dict(obs_spec=mt.ObservationSpec(as_dict=False, sites_pos=("imu", "thrust1"), bodies_pos=("x2",)), batch=64)
+    a = mt.Env.from_xml_path(MODELS["drone2"], controller=mt.RandomCtrlController(seed=2, scale=0.3), **kw)
+    b = mt.Env.from_xml_path(MODELS["drone2"], controller=mt.RandomCtrlController(seed=2, scale=0.3), **kw)
+    obs_ring = a.rollout(20, obs_every=1)                                         # [20, 64, dim] on the GPU
+    last = None
+    for _ in range(20):
+        last = b.step()
+    assert np.array_equal(np.array(a.data.qpos), np.array(b.data.qpos))
+    assert obs_ring.shape == (20, 64, 3 + 7 + 6 + 6)
+    assert obs_ring[-1].cpu().numpy() == pytest.approx(last.obs, abs=1e-6)        # bodies_pos | qpos | qvel | sites_pos
+    assert runtime.run_passive_headless(a, max_steps=30) == 30 and a.data.time[0] == pytest.approx(0.5)
+    # host RandomCtrlController.__call__ writes exactly the device's ctrl
+    c = mt.Env.from_xml_path(MODELS["drone2"], batch=4)
+    ctl = mt.RandomCtrlController(seed=2, scale=0.3)
+    ctl.prepare(c.model, c.data)
+    ctl(c.model, c.data, 0.0)
+    d = mt.Env.from_xml_path(MODELS["drone2"], controller=mt.RandomCtrlController(seed=2, scale=0.3), batch=4)
+    d.rollout(1)
+    assert np.array(d.data.ctrl) == pytest.approx(np.array(c.data.ctrl), abs=1e-6)
+
+
+def test_batched_env_shapes_and_linearization():
+    """BASELINE config 4 shape contract: cartpole needs_linearization, batch 512 -> A [512,4,4], B [512,4,1]."""
+    class Lin(_Ctl):
+        def __call__(self, model, data, t):
+            data.ctrl[...] = 0.0
+
+    env = mt.Env.from_xml_path(MODELS["cartpole"], controller=Lin(mt.ControllerCapabilities(needs_linearization=True)), batch=512)
+    r = env.step()
+    assert r.info["A"].shape == (512, 4, 4) and r.info["B"].shape == (512, 4, 1)
+    assert r.obs["qpos"].shape == (512, 2)
+    assert np.allclose(r.info["A"][0], r.info["A"][511])          # identical replicas -> identical linearisation

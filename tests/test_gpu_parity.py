@@ -1,0 +1,314 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the float64 CPU oracle on the
+same seeded inputs and against the committed fixtures.  Tolerances (stated per test):
+  * float64 instantiation of the kernels: rounding-level agreement (<= 1e-9), also through contacts;
+  * fp32 product path: single-step (teacher-forced) |dqpos| <= 2e-6 from identical states; free-running
+    drift <= 1e-4 over the smooth / pre-contact horizon (SURVEY.md §7 hard part 2: contact-rich
+    trajectories are chaotic, fp32-vs-f64 drift there is reported, not bounded at 1e-4).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from mujoco_template_amd._capi import CTRL_KEEP, CTRL_RANDOM, CTRL_ZERO, BatchSim, DeviceModel  # noqa: E402
+from mujoco_template_amd import mjcf  # noqa: E402
+from oracle import mjo  # noqa: E402
+from tests.conftest import BASE_XML, MODELS  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCALE = {"pendulum": 1.0, "cartpole": 0.005, "humanoid": 1.0, "drone2": 0.3, "base": 1.0}
+
+
+@pytest.fixture(scope="module")
+def world():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cm = mjcf.compile_xml_string(BASE_XML) if name == "base" else mjcf.compile_xml_path(MODELS[name])
+            cache[name] = (cm, mjo.OracleModel(cm), DeviceModel(cm))
+        return cache[name]
+
+    return get
+
+
+def random_states(cm, od, B, seed, qs=0.05, vs=0.2):
+    rng = np.random.default_rng(seed)
+    q = np.stack([od.integrate_pos(cm.qpos0, rng.normal(size=cm.nv) * qs, 1.0) for _ in range(B)])
+    v = rng.normal(size=(B, cm.nv)) * vs
+    u = rng.uniform(-1, 1, size=(B, cm.nu))
+    return q, v, u
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "drone2", "humanoid", "base"])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_forward_phases_match_oracle(world, name, dtype):
+    cm, om, dm = world(name)
+    B = 16
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    q, v, u = random_states(cm, ods[0], B, 1)
+    q[0], v[0], u[0] = cm.qpos0, 0, 0                      # env 0: the reset state (standing humanoid: 32 rows)
+    sim = BatchSim(dm, B, dtype=dtype)
+    sim.set("qpos", q); sim.set("qvel", v); sim.set("ctrl", u)
+    sim.debug_forward()
+    for e, od in enumerate(ods):
+        od.qpos[:] = q[e]; od.qvel[:] = v[e]; od.ctrl[:] = u[e]; od.forward()
+    tol = 1e-10 if dtype == "float64" else 2e-5
+    for key in ("qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qacc_smooth", "qfrc_constraint"):
+        ref = np.stack([getattr(od, key) for od in ods])
+        got = sim.debug_get(key)
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), key
+    ref = np.stack([od.qacc for od in ods])
+    assert np.abs(sim.get("qacc") - ref).max() <= tol * max(1.0, np.abs(ref).max())
+    for key in ("xpos", "xipos", "site_xpos", "geom_xpos", "subtree_com"):
+        ref = np.stack([getattr(od, key) for od in ods])
+        assert np.abs(sim.get(key) - ref).max() <= (1e-12 if dtype == "float64" else 2e-6), key
+    cn = sim.counters()
+    assert cn["nefc"].tolist() == [od.counters()["nefc"] for od in ods]
+    assert cn["ncon"].tolist() == [od.counters()["ncon"] for od in ods]
+    # constraint rows: same order, Jacobian / aref / D identical up to rounding
+    nv = cm.nv
+    J = sim.debug_get("efc_J").reshape(B, sim.nefcmax, nv)
+    ar, D, typ = sim.debug_get("efc_aref"), sim.debug_get("efc_D"), sim.debug_get("efc_type")
+    for e, od in enumerate(ods):
+        n = od.counters()["nefc"]
+        if n:
+            rt = 1e-9 if dtype == "float64" else 1e-4
+            assert np.abs(J[e, :n] - od.efc_J.reshape(n, nv)).max() <= rt * 10
+            assert np.abs(ar[e, :n] - od.efc_aref).max() <= rt * max(1.0, np.abs(od.efc_aref).max())
+            assert np.abs(D[e, :n] - od.efc_D).max() <= rt * np.abs(od.efc_D).max()
+            assert typ[e, :n].tolist() == od.efc_type().tolist()
+
+
+@pytest.mark.parametrize("name,steps", [("pendulum", 200), ("cartpole", 200), ("drone2", 100), ("humanoid", 150)])
+def test_float64_free_running_matches_oracle(world, name, steps):
+    """Same kernels in double: rounding-level agreement over whole trajectories, contacts included."""
+    cm, om, dm = world(name)
+    B = 8
+    sim = BatchSim(dm, B, dtype="float64")
+    od0 = mjo.OracleData(om)
+    q, v, _ = random_states(cm, od0, B, 2, qs=0.02, vs=0.1)
+    sim.set("qpos", q); sim.set("qvel", v)
+    sim.rollout(steps, CTRL_RANDOM, seed=5, ctrl_scale=SCALE[name])
+    qT, vT = mjo.rollout_batch(om, B, steps, seed=5, scale=SCALE[name], nthreads=4, qpos_init=q, qvel_init=v)
+    assert np.abs(sim.get("qpos") - qT).max() < 1e-9
+    assert np.abs(sim.get("qvel") - vT).max() < 1e-7
+    assert sim.get("time")[:, 0] == pytest.approx(steps * cm.timestep)
+    cn = sim.counters()
+    assert cn["efc_dropped"].sum() == 0 and cn["con_dropped"].sum() == 0
+
+
+@pytest.mark.parametrize("name,steps", [("pendulum", 100), ("cartpole", 100), ("drone2", 100), ("humanoid", 100), ("base", 100)])
+def test_fp32_teacher_forced_single_step(world, name, steps):
+    """fp32 product path from identical states: one-step |dqpos| <= 2e-6, |dqvel| <= 2e-3 * max(1,|qvel|)."""
+    cm, om, dm = world(name)
+    B = 8
+    sim = BatchSim(dm, B, dtype="float32")
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    q, v, _ = random_states(cm, ods[0], B, 3, qs=0.02, vs=0.1)
+    for e, od in enumerate(ods):
+        od.qpos[:] = q[e]; od.qvel[:] = v[e]
+    worst_q = worst_v = 0.0
+    for s in range(steps):
+        u = np.stack([od.random_ctrl(9, e, s, SCALE[name]) for e, od in enumerate(ods)])
+        sim.set("qpos", np.stack([od.qpos for od in ods])); sim.set("qvel", np.stack([od.qvel for od in ods]))
+        sim.set("qacc_warmstart", np.stack([od.qacc_warmstart for od in ods])); sim.set("ctrl", u)
+        sim.step(1)
+        for e, od in enumerate(ods):
+            od.ctrl[:] = u[e]; od.step()
+        qo, vo = np.stack([od.qpos for od in ods]), np.stack([od.qvel for od in ods])
+        worst_q = max(worst_q, np.abs(sim.get("qpos") - qo).max())
+        worst_v = max(worst_v, (np.abs(sim.get("qvel") - vo) / np.maximum(1.0, np.abs(vo))).max())
+    assert worst_q <= 2e-6, worst_q
+    assert worst_v <= 2e-3, worst_v
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "humanoid", "drone2"])
+def test_against_committed_golden(world, name):
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    cm, om, dm = world(name)
+    B, nstep, seed, scale = g["qpos0"].shape[0], int(g["nstep"]), int(g["seed"]), float(g["scale"])
+    for dtype, tq in (("float64", 1e-8), ("float32", 2e-4)):
+        sim = BatchSim(dm, B, dtype=dtype)
+        sim.set("qpos", g["qpos0"]); sim.set("qvel", g["qvel0"])
+        sim.rollout(1, CTRL_RANDOM, seed=seed, ctrl_scale=scale)       # writes the step-0 ctrl
+        sim.set("qpos", g["qpos0"]); sim.set("qvel", g["qvel0"]); sim.set("qacc_warmstart", np.zeros((B, cm.nv))); sim.set("time", np.zeros((B, 1)))
+        sim.forward()
+        ft = 1e-8 if dtype == "float64" else 3e-5
+        for k in ("xpos", "subtree_com"):
+            assert np.abs(sim.get(k) - g["fwd_" + k]).max() <= max(ft, 1e-9), k
+        ref = g["fwd_qacc"]
+        assert np.abs(sim.get("qacc") - ref).max() <= ft * max(1.0, np.abs(ref).max())
+        assert sim.counters()["nefc"].tolist() == g["fwd_nefc"].tolist()
+        sim.rollout(nstep, CTRL_RANDOM, seed=seed, ctrl_scale=scale)
+        assert np.abs(sim.get("qpos") - g["qposT"]).max() <= tq, dtype
+
+
+def test_cartpole_config2_smooth_regime_drift(world):
+    """BASELINE config 2: cartpole B=1024 random-ctrl rollout, fp32, qpos drift vs the CPU oracle <= 1e-4 over 1000
+    steps in the smooth regime (|force| <= 0.25 N: pole swings, no floor / slider-limit contact)."""
+    cm, om, dm = world("cartpole")
+    B, T = 1024, 1000
+    rng = np.random.default_rng(0)
+    q = np.zeros((B, 2)); q[:, 1] = rng.uniform(-0.05, 0.05, size=B) + np.pi     # hanging pole: bounded, non-chaotic motion
+    sim = BatchSim(dm, B, dtype="float32")
+    sim.set("qpos", q)
+    sim.rollout(T, CTRL_RANDOM, seed=1, ctrl_scale=0.005)
+    qT, _ = mjo.rollout_batch(om, B, T, seed=1, scale=0.005, nthreads=8, qpos_init=q)
+    err = np.abs(sim.get("qpos") - qT).max()
+    assert sim.counters()["nefc"].max() == 0
+    assert err <= 1e-4, err
+
+
+def test_fused_rollout_equals_stepwise_and_is_deterministic(world):
+    cm, om, dm = world("humanoid")
+    B, T = 64, 30
+    a, b, c = (BatchSim(dm, B, dtype="float32") for _ in range(3))
+    a.rollout(T, CTRL_RANDOM, seed=4)
+    for s in range(T):
+        b.rollout(1, CTRL_RANDOM, seed=4, step0=s)
+    c.rollout(10, CTRL_RANDOM, seed=4); c.rollout(20, CTRL_RANDOM, seed=4, step0=10)
+    qa = a.get("qpos")
+    assert np.array_equal(qa, b.get("qpos")) and np.array_equal(qa, c.get("qpos"))
+    assert np.array_equal(a.get("qvel"), b.get("qvel"))
+
+
+def test_shard_invariance_env0(world):
+    """Random ctrl is keyed by the GLOBAL env index: 1 shard of 8 == 2 shards of 4 (bitwise)."""
+    cm, om, dm = world("humanoid")
+    full = BatchSim(dm, 8, dtype="float32")
+    lo, hi = BatchSim(dm, 4, dtype="float32", env0=0), BatchSim(dm, 4, dtype="float32", env0=4)
+    for s in (full, lo, hi):
+        s.rollout(40, CTRL_RANDOM, seed=11)
+    assert np.array_equal(full.get("qpos"), np.concatenate([lo.get("qpos"), hi.get("qpos")]))
+    assert not np.array_equal(lo.get("qpos"), hi.get("qpos"))
+
+
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_lanes_per_env_variants_agree(world, lanes):
+    cm, om, dm = world("drone2")
+    sim = BatchSim(dm, 32, dtype="float64", lanes=lanes)
+    sim.reset(0)                                             # hover keyframe
+    assert sim.get("qpos")[0] == pytest.approx(cm.key_qpos[0])
+    assert sim.get("ctrl")[0] == pytest.approx(cm.key_ctrl[0])
+    sim.step(50)
+    assert np.abs(sim.get("qpos") - cm.key_qpos[0]).max() < 1e-12     # K1: hover is a fixed point
+    sim.reset(-1)                                            # rest on the floor: 4 box contacts settle
+    sim.rollout(300, CTRL_ZERO)
+    od = mjo.OracleData(om)
+    od.step(300)
+    assert np.abs(sim.get("qpos")[0] - od.qpos).max() < 1e-9
+    assert sim.counters()["ncon"][0] == od.counters()["ncon"] > 0
+
+
+def test_caps_drop_the_same_rows_as_the_oracle(world):
+    cm, om0, dm = world("humanoid")
+    om = mjo.OracleModel(cm)
+    om.set_limits(6, 20)
+    od = mjo.OracleData(om)
+    sim = BatchSim(dm, 4, dtype="float64", nconmax=6, nefcmax=20)
+    od.forward(); sim.forward()
+    cn = sim.counters()
+    assert (cn["ncon"][0], cn["nefc"][0], cn["con_dropped"][0]) == (6, 20, 2)
+    assert np.abs(sim.get("qacc")[0] - od.qacc).max() < 1e-9
+
+
+def test_bad_state_guard(world):
+    cm, om, dm = world("cartpole")
+    sim = BatchSim(dm, 4, dtype="float32")
+    q = np.zeros((4, 2)); q[2, 0] = np.nan
+    sim.set("qpos", q)
+    sim.step(1)
+    cn = sim.counters()
+    assert cn["warn_badqpos"].tolist() == [0, 0, 1, 0]
+    assert np.isfinite(sim.get("qpos")).all()
+
+
+@pytest.mark.parametrize("name,B,eps", [("pendulum", 8, 1e-6), ("cartpole", 512, 1e-6), ("drone2", 8, 1e-6), ("humanoid", 4, 1e-6), ("base", 4, 1e-6)])
+def test_transition_fd_matches_oracle(world, name, B, eps):
+    """BASELINE config 4 (cartpole B=512, eps 1e-6 centred): device float64 FD vs oracle FD."""
+    cm, om, dm = world(name)
+    od = mjo.OracleData(om)
+    q, v, u = random_states(cm, od, B, 7, qs=0.02, vs=0.1)
+    u *= 0.5
+    if name == "humanoid":
+        q[:, 2] += 0.5                                       # airborne: keep FD away from contact switching
+    sim = BatchSim(dm, B, dtype="float32")
+    sim.set("qpos", q); sim.set("qvel", v); sim.set("ctrl", u)
+    A, Bm = sim.transition_fd(eps, True)
+    q32, v32, u32 = sim.get("qpos"), sim.get("qvel"), sim.get("ctrl")     # the fp32-rounded state the device linearised about
+    worst = 0.0
+    for e in range(min(B, 8)):
+        od.reset(); od.qpos[:] = q32[e]; od.qvel[:] = v32[e]; od.ctrl[:] = u32[e]
+        Ao, Bo = od.transition_fd(eps, True)
+        worst = max(worst, np.abs(A[e] - Ao).max() / max(1.0, np.abs(Ao).max()), np.abs(Bm[e] - Bo).max() / max(1.0, np.abs(Bo).max()))
+    assert worst < 5e-5, worst
+    assert A.shape == (B, 2 * cm.nv, 2 * cm.nv) and Bm.shape == (B, 2 * cm.nv, cm.nu)
+    assert np.array_equal(sim.get("qpos"), q32)              # state untouched
+
+
+def test_transition_fd_respects_ctrlrange(world):
+    cm, om, dm = world("drone2")
+    sim = BatchSim(dm, 2, dtype="float64")
+    sim.reset(0)
+    u = sim.get("ctrl"); u[1, :] = 0.0                       # at the lower bound of ctrlrange [0, 13]: one-sided difference
+    sim.set("ctrl", u)
+    A, Bm = sim.transition_fd(1e-6, True)
+    od = mjo.OracleData(om); od.reset_keyframe(0); od.ctrl[:] = 0.0
+    Ao, Bo = od.transition_fd(1e-6, True)
+    assert np.abs(Bm[1] - Bo).max() < 1e-5 * max(1.0, np.abs(Bo).max())
+    assert np.abs(Bm[1]).max() > 0
+
+
+def test_jacobians_match_oracle(world):
+    cm, om, dm = world("humanoid")
+    B = 6
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    q, _, _ = random_states(cm, ods[0], B, 9, qs=0.2)
+    sim = BatchSim(dm, B, dtype="float64")
+    sim.set("qpos", q)
+    foot, torso = cm.name2id(mjcf.OBJ_BODY, "foot_left"), cm.name2id(mjcf.OBJ_BODY, "torso")
+    kinds, ids = [1, 2, 3, 3], [foot, foot, torso, foot]
+    jp, jr = sim.jac(kinds, ids)
+    for e, od in enumerate(ods):
+        od.qpos[:] = q[e]; od.forward()
+        for r, (k, i) in enumerate(zip(kinds, ids)):
+            op, orr = od.jac(k, i)
+            assert np.abs(jp[e, r] - op).max() < 1e-12
+            if k < 3:
+                assert np.abs(jr[e, r] - orr).max() < 1e-12
+    cmd, omd, dmd = world("drone2")
+    simd = BatchSim(dmd, 2, dtype="float32")
+    jp, jr = simd.jac([0], [cmd.name2id(mjcf.OBJ_SITE, "thrust3")])
+    odd = mjo.OracleData(omd); odd.forward()
+    op, orr = odd.jac(0, cmd.name2id(mjcf.OBJ_SITE, "thrust3"))
+    assert np.abs(jp[0, 0] - op).max() < 1e-7 and np.abs(jr[0, 0] - orr).max() < 1e-7
+
+
+def test_full_size_humanoid_properties(world):
+    """BASELINE config 3 at full size (B=4096, 1000 steps, fp32): size-independent properties."""
+    cm, om, dm = world("humanoid")
+    B, T = 4096, 1000
+    runs = []
+    for _ in range(2):
+        sim = BatchSim(dm, B, dtype="float32")
+        for c in range(0, T, 250):
+            sim.rollout(250, CTRL_RANDOM, seed=0, step0=c)
+        runs.append((sim.get("qpos"), sim.get("qvel"), sim.counters(), sim.get("time")))
+    q, v, cn, t = runs[0]
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-5          # unit root quaternions
+    assert t[:, 0] == pytest.approx(T * cm.timestep, rel=1e-9)
+    assert cn["efc_dropped"].sum() == 0 and cn["con_dropped"].sum() == 0       # caps never hit
+    assert (cn["warn_badqpos"] + cn["warn_badqvel"] + cn["warn_badqacc"]).sum() == 0
+    assert q[:, 2].min() > -0.05 and q[:, 2].max() < 1.6                       # nobody tunnelled through the floor or flew away
+    rng = cm.jnt_range[1:]                                                     # hinge limits hold up to soft-constraint slack
+    assert (q[:, 7:] > rng[:, 0] - 0.35).all() and (q[:, 7:] < rng[:, 1] + 0.35).all()
+    assert np.array_equal(q, runs[1][0]) and np.array_equal(v, runs[1][1])     # bitwise deterministic
+    # a sample of environments against the oracle for the first 60 steps (pre-chaos horizon)
+    sim = BatchSim(dm, 8, dtype="float32")
+    sim.rollout(60, CTRL_RANDOM, seed=0)
+    qo, _ = mjo.rollout_batch(om, 8, 60, seed=0, nthreads=4)
+    assert np.abs(sim.get("qpos") - qo).max() < 5e-4

@@ -1,0 +1,133 @@
+"""Host-side logic that needs no GPU: counter-based RNG parity (numpy vs C), sharding, obs layout,
+controllers, manifold helpers, reference error behaviour, and the world_size-2 gloo all-gather."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mujoco_template_amd as mt
+from mujoco_template_amd import mj, mjcf
+from mujoco_template_amd.controllers import philox_uniform
+from mujoco_template_amd.distributed import shard_range
+from tests.conftest import BASE_XML
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_philox_numpy_matches_oracle_c(oracle):
+    m, d = oracle("humanoid")
+    cm = m.compiled
+    for seed, step in ((0, 0), (7, 123), (2**31 + 5, 99999)):
+        u = philox_uniform(seed, np.arange(5) + 11, step, cm.nu)
+        for e in range(5):
+            ctrl = d.random_ctrl(seed, 11 + e, step, 1.0)
+            lo, hi = cm.actuator_ctrlrange[:, 0], cm.actuator_ctrlrange[:, 1]
+            assert 0.5 * (lo + hi) + 0.5 * (hi - lo) * (2 * u[e] - 1) == pytest.approx(ctrl, abs=1e-15)
+    assert ((u >= 0) & (u < 1)).all()
+
+
+def test_shard_range_partitions_batch():
+    for B, W in ((4096, 8), (2048, 8), (10, 4), (3, 8), (4096, 1)):
+        blocks = [shard_range(B, r, W) for r in range(W)]
+        assert sum(c for _, c in blocks) == B
+        pos = 0
+        for e0, c in blocks:
+            assert e0 == pos
+            pos += c
+    with pytest.raises(ValueError):
+        shard_range(8, 3, 2)
+
+
+def test_manifold_helpers_roundtrip():
+    model = mj.MjModel.from_xml_path(os.path.join(ROOT, "models", "humanoid.xml"))
+    rng = np.random.default_rng(0)
+    q0 = np.array(model.qpos0)
+    v = rng.normal(size=model.nv) * 0.4
+    q1 = q0.copy()
+    mj.mj_integratePos(model, q1, v, 0.5)
+    assert np.linalg.norm(q1[3:7]) == pytest.approx(1.0)
+    back = np.zeros(model.nv)
+    mj.mj_differentiatePos(model, back, 0.5, q0, q1)
+    assert back == pytest.approx(v, abs=1e-12)
+
+
+def test_manifold_helpers_match_oracle(oracle):
+    m, d = oracle("drone2")
+    model = mj.MjModel(m.compiled)
+    rng = np.random.default_rng(1)
+    v = rng.normal(size=6)
+    q = np.array(m.compiled.qpos0)
+    mj.mj_integratePos(model, q, v, 0.3)
+    assert q == pytest.approx(d.integrate_pos(m.compiled.qpos0, v, 0.3), abs=1e-14)
+
+
+def test_name_lookup_and_model_tables():
+    model = mj.MjModel.from_xml_string(BASE_XML)
+    assert mj.mj_name2id(model, mj.mjtObj.mjOBJ_SITE, "tip") == 0
+    assert mj.mj_name2id(model, mj.mjtObj.mjOBJ_SITE, "nope") == -1
+    assert mj.mj_id2name(model, mj.mjtObj.mjOBJ_ACTUATOR, 1) == "pos_act"
+    assert model.nu == 2 and model.actuator_ctrlrange.shape == (2, 2)
+    with pytest.raises(mt.NameLookupError):
+        mt.ObservationExtractor(model, mt.ObservationSpec(sites_pos=("missing",)))
+    ex = mt.ObservationExtractor(model, mt.ObservationSpec(include_ctrl=True, include_time=True, sites_pos=("tip",), bodies_pos=("torso",)))
+    assert ex.obs_dim == 1 + 1 + 2 + 1 + 3 + 3
+
+
+def test_jacobian_token_grammar():
+    from mujoco_template_amd.jacobians import _parse_jacobian_token
+
+    assert _parse_jacobian_token("site:tip") == ("site", "tip")
+    assert _parse_jacobian_token("subtreecom:torso") == ("subtreecom", "torso")
+    assert _parse_jacobian_token("com") == ("com", None)
+    with pytest.raises(mt.ConfigError):
+        _parse_jacobian_token("frame:x")
+
+
+def test_compat_report_matches_reference_rules():
+    model = mj.MjModel.from_xml_string(BASE_XML)
+    caps = mt.ControllerCapabilities(control_space=mt.ControlSpace.POSITION, actuator_groups=(1,))
+    rep = mt.check_controller_compat(model, caps, np.array([True, True]))
+    assert rep.ok
+    assert any("lacks ctrlrange" in w for w in rep.warnings)          # actuator 0 is a torque motor
+    assert any("beyond the controller request" in w for w in rep.warnings)
+    rep = mt.check_controller_compat(model, caps, np.array([False, False]))
+    assert not rep.ok
+    with pytest.raises(mt.CompatibilityError):
+        rep.assert_ok()
+    with pytest.raises(mt.ConfigError):
+        mt.check_controller_compat(model, caps, np.array([True]))
+
+
+def test_controller_protocol_objects():
+    z = mt.ZeroController()
+    assert z.device_ctrl_mode == "zero" and z.capabilities.control_space == mt.ControlSpace.TORQUE
+    r = mt.RandomCtrlController(seed=3, scale=0.5)
+    assert r.device_ctrl_mode == "random"
+
+
+def test_gloo_world_size_2_all_gather_obs(tmp_path):
+    """The N>1 path (shard_range + all_gather_obs) under torch.distributed/gloo with two CPU ranks."""
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from mujoco_template_amd.distributed import init_process_group, shard_range, all_gather_obs, world\n"
+        "rank, ws, _ = world()\n"
+        "assert init_process_group('gloo')\n"
+        "B, dim = 10, 7\n"
+        "full = torch.arange(3 * B * dim, dtype=torch.float32).reshape(3, B, dim)\n"
+        "e0, c = shard_range(B, rank, ws)\n"
+        "out = all_gather_obs(full[:, e0:e0 + c].clone())\n"
+        "assert out.shape == full.shape and torch.equal(out, full), (rank, out.shape)\n"
+        "e0, c = shard_range(9, rank, ws)                      # ragged shards: 5 + 4\n"
+        "out = all_gather_obs(full[:, e0:e0 + c].clone())\n"
+        "assert torch.equal(out, full[:, :9])\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -1,0 +1,87 @@
+"""The HIP kernel SOURCE (csrc/mjb_device.hpp) executed on the host — one thread per lane, real
+barriers (tests/hostemu) — against the oracle.  Checks lane-strided indexing, scans, shuffles and
+sync placement without a GPU; the GPU parity tests (-m gpu) run the real kernels.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import mjo
+from tests.hostemu.emu import EmuEnv
+
+
+def _pair(compiled, name, G, use_double=True):
+    cm = compiled(name)
+    return cm, mjo.OracleData(mjo.OracleModel(cm)), EmuEnv(cm, G=G, use_double=use_double)
+
+
+@pytest.mark.parametrize("name,G", [("pendulum", 8), ("cartpole", 8), ("drone2", 16), ("humanoid", 16), ("humanoid", 64)])
+def test_forward_phases_match_oracle(compiled, name, G):
+    cm, od, e = _pair(compiled, name, G)
+    rng = np.random.default_rng(0)
+    q = od.integrate_pos(cm.qpos0, rng.normal(size=cm.nv) * 0.1, 1.0)
+    v = rng.normal(size=cm.nv) * 0.5
+    u = rng.uniform(-1, 1, size=cm.nu)
+    od.qpos[:] = q; od.qvel[:] = v; od.ctrl[:] = u
+    e.qpos[:] = q; e.qvel[:] = v; e.ctrl[:cm.nu] = u
+    od.forward(); e.forward()
+    for k in ("xpos", "xipos", "subtree_com", "cdof", "cinert", "cvel", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qacc_smooth", "qfrc_constraint", "qacc"):
+        a, b = getattr(e, k), getattr(od, k)
+        scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+        assert np.abs(a[:b.size] - b).max() <= 1e-11 * scale, k
+    assert e.counters[1] == od.counters()["nefc"]
+
+
+@pytest.mark.parametrize("name,G,steps,scale", [("pendulum", 8, 60, 1.0), ("cartpole", 8, 60, 0.01), ("drone2", 16, 40, 0.3), ("humanoid", 16, 12, 1.0)])
+def test_free_running_float64_tracks_oracle(compiled, name, G, steps, scale):
+    cm, od, e = _pair(compiled, name, G)
+    if name == "pendulum":
+        od.qpos[0] = e.qpos[0] = 1.0
+    for s in range(steps):
+        u = od.random_ctrl(0, 0, s, scale)
+        od.ctrl[:] = u; e.ctrl[:cm.nu] = u
+        od.step(); e.step()
+        c = od.counters()
+        assert (e.counters[0], e.counters[1], e.counters[2]) == (c["ncon"], c["nefc"], c["solver_niter"])
+    assert np.abs(e.qpos - od.qpos).max() < 1e-10
+    assert np.abs(e.qvel - od.qvel).max() < 1e-8
+    assert e.time[0] == pytest.approx(od.time)
+
+
+def test_humanoid_contacts_wave64_and_fp32(compiled):
+    """Standing humanoid: 8 foot contacts -> 32 pyramidal rows; G=64 uses the shuffle triangular solve."""
+    cm, od, e = _pair(compiled, "humanoid", 64)
+    od.forward(); e.forward()
+    assert e.counters[0] == 8 and e.counters[1] == 32
+    nv = cm.nv
+    J_o = od.efc_J.reshape(-1, nv)
+    J_e = e.efc_J[: 32 * nv].reshape(32, nv)
+    assert np.abs(J_e - J_o).max() < 1e-12
+    assert np.abs(e.efc_aref[:32] - od.efc_aref).max() < 1e-9
+    assert np.abs(e.efc_D[:32] - od.efc_D).max() < 1e-9 * od.efc_D.max()
+    assert np.abs(e.qacc - od.qacc).max() < 1e-9
+    # fp32 instantiation of the same source: single-step error at fp32 level
+    e32 = EmuEnv(cm, G=16, use_double=False)
+    e32.step()
+    od.step()
+    assert np.abs(e32.qpos - od.qpos).max() < 2e-6
+
+
+def test_row_cap_overflow_matches_oracle(compiled):
+    """Constraint-row / contact caps: both sides drop the same tail rows and count them."""
+    cm = compiled("humanoid")
+    om = mjo.OracleModel(cm)
+    om.set_limits(6, 20)
+    od = mjo.OracleData(om)
+    e = EmuEnv(cm, G=16, use_double=True, ncon_max=6, nefc_max=20)
+    od.forward(); e.forward()
+    c = od.counters()
+    assert (c["ncon"], c["nefc"]) == (6, 20) and c["ncon_dropped"] == 2
+    assert (e.counters[0], e.counters[1]) == (6, 20) and e.counters[3] == 2
+    assert np.abs(e.qacc - od.qacc).max() < 1e-9
+
+
+def test_bad_state_resets_like_mj_checkpos(compiled):
+    cm, od, e = _pair(compiled, "cartpole", 8)
+    od.qpos[0] = e.qpos[0] = np.nan
+    od.step(); e.step()
+    assert od.counters()["warn_badqpos"] == 1 and e.counters[5] == 1
+    assert np.isfinite(e.qpos).all() and np.abs(e.qpos - od.qpos).max() < 1e-12

@@ -1,0 +1,286 @@
+"""Analytic known-answer tests that pin the CPU oracle WITHOUT the real mujoco library
+(SURVEY.md §8c K1-K8).  "Parity unpinned" against MuJoCo itself: these anchors check the
+restated algorithm against closed-form mechanics.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from mujoco_template_amd import mjcf
+from oracle import mjo
+
+G = 9.81
+
+
+def _pole():
+    """Cart-pole pole: capsule r=0.025, half-length 0.3, density 300 (cartpole.xml:25) -> mass, inertia about its com."""
+    r, h, rho = 0.025, 0.3, 300.0
+    mc_, ms_ = rho * math.pi * r * r * 2 * h, rho * 4.0 / 3.0 * math.pi * r ** 3
+    I = mc_ * (3 * r * r + 4 * h * h) / 12 + ms_ * (0.4 * r * r + h * h + 0.75 * h * r)
+    return mc_ + ms_, I
+
+
+def test_k1_drone_hover_is_a_fixed_point(oracle):
+    m, d = oracle("drone2")
+    d.reset_keyframe(0)
+    d.forward()
+    assert np.abs(d.qacc).max() < 1e-12            # thrust 4 * 3.2495625 N = m g exactly
+    q0 = d.qpos.copy()
+    d.step(200)
+    assert np.abs(d.qpos - q0).max() < 1e-12
+    assert d.counters()["ncon"] == 0
+
+
+def test_k2_pendulum_period_energy_and_bottom_speed(oracle):
+    m, d = oracle("pendulum")
+    mass, I, L = 0.7941946228, 0.06809102997, 0.25
+    d.qpos[0] = 0.01
+    d.forward()
+    assert d.qacc[0] == pytest.approx(-mass * G * L * math.sin(0.01) / I, rel=1e-9)
+    # small-angle period 2 pi sqrt(I / (m g l)): count zero crossings over 20 s
+    cross, prev = [], d.qpos[0]
+    for _ in range(4000):
+        d.step()
+        if prev < 0 <= d.qpos[0]:
+            cross.append(d.time)
+        prev = d.qpos[0]
+    period = np.diff(cross).mean()
+    assert period == pytest.approx(2 * math.pi * math.sqrt(I / (mass * G * L)), rel=2e-3)
+    # released from 90 degrees: omega at the bottom = sqrt(2 m g l / I); RK4 conserves energy to ~1e-9
+    d.reset()
+    d.qpos[0] = math.pi / 2
+    wmax, e0 = 0.0, None
+    for _ in range(800):
+        d.step()
+        wmax = max(wmax, abs(d.qvel[0]))
+        e = 0.5 * I * d.qvel[0] ** 2 - mass * G * L * math.cos(d.qpos[0])
+        e0 = e if e0 is None else e0
+        assert abs(e - e0) < 1e-7
+    assert wmax == pytest.approx(math.sqrt(2 * mass * G * L / I), rel=1e-5)
+    assert wmax == pytest.approx(7.563765, rel=1e-5)
+
+
+def test_k3_cartpole_closed_form_dynamics(oracle):
+    m, d = oracle("cartpole")
+    mc, l = 4.8, 0.3                                     # pole com 0.3 m above the hinge
+    mp, Ip = _pole()
+    th, xd, thd, u = 0.3, 0.5, -0.7, 0.2
+    d.qpos[:] = [0.1, th]
+    d.qvel[:] = [xd, thd]
+    d.ctrl[0] = u
+    d.forward()
+    M = np.array([[mc + mp, mp * l * math.cos(th)], [mp * l * math.cos(th), Ip + mp * l * l]])
+    assert d.qM.reshape(2, 2) == pytest.approx(M, rel=1e-6)
+    bias = np.array([-mp * l * math.sin(th) * thd ** 2, -mp * G * l * math.sin(th)])
+    assert d.qfrc_bias == pytest.approx(bias, rel=1e-6)
+    tau = np.array([50 * u - 1.0 * xd, -0.1 * thd])
+    qacc = np.linalg.solve(M, tau - bias)
+    assert d.qacc == pytest.approx(qacc, rel=1e-6)
+    # Euler with implicit joint damping: (M + h D) a = tau - bias
+    h, D = 0.01, np.diag([1.0, 0.1])
+    a_imp = np.linalg.solve(M + h * D, tau - bias)
+    v1 = np.array([xd, thd]) + h * a_imp
+    d.step()
+    assert d.qvel == pytest.approx(v1, rel=1e-6)
+    assert d.qpos == pytest.approx(np.array([0.1, th]) + h * v1, rel=1e-9)
+    assert d.time == pytest.approx(0.01)
+
+
+def test_k3b_cartpole_slider_limit_engages(oracle):
+    m, d = oracle("cartpole")
+    d.qpos[0] = 2.05            # 5 cm past the +2 m limit
+    d.forward()
+    c = d.counters()
+    assert c["nefc"] == 1 and c["ncon"] == 0
+    assert d.efc_J == pytest.approx([-1.0, 0.0])
+    assert d.efc_pos == pytest.approx([-0.05])
+    assert d.qacc[0] < 0 and d.qfrc_constraint[0] < 0
+
+
+def test_k4_drone_free_fall_and_unit_quaternion(oracle, tmp_path, models):
+    """Without the fluid (density = viscosity = 0) a tumbling drone is in exact free fall; with the fluid it is slower."""
+    import os
+    import shutil
+
+    src = os.path.dirname(models["drone2"])
+    for f in ("scene.xml", "x2.xml"):
+        shutil.copy(os.path.join(src, f), tmp_path / f)
+    x2 = (tmp_path / "x2.xml").read_text().replace('density="1.225" viscosity="1.8e-5"', "")
+    (tmp_path / "x2.xml").write_text(x2)
+    cm = mjcf.compile_xml_path(str(tmp_path / "scene.xml"))
+    assert cm.density == 0 and cm.viscosity == 0
+    vac = mjo.OracleData(mjo.OracleModel(cm))
+    _, air = oracle("drone2")
+    w0 = np.array([0.3, -0.2, 0.1])
+    com = {}
+    for key, d in (("vac", vac), ("air", air)):
+        d.reset()
+        d.qpos[2] += 5.0                       # high above the floor: no contacts
+        d.qvel[3:6] = w0                       # tumbling about the frame origin (the com sits 5.4 cm above it)
+        d.forward()
+        c0 = d.subtree_com[3:6].copy()
+        for _ in range(50):
+            d.step()
+            assert abs(np.linalg.norm(d.qpos[3:7]) - 1) < 1e-12
+            assert d.counters()["ncon"] == 0
+        d.forward()
+        com[key] = (c0, d.subtree_com[3:6].copy(), d.time)
+    c0, c1, t = com["vac"]
+    v0 = np.cross(w0, cm.body_ipos[1])         # com velocity at t = 0 (identity orientation)
+    h = cm.timestep
+    assert c1 == pytest.approx(c0 + v0 * t + np.array([0, 0, -0.5 * G * t * (t + h)]), abs=1e-4)   # ballistic com up to the O(h) error of integrating a spinning offset origin
+    assert vac.qvel[3:6] != pytest.approx(w0)                         # torque-free precession of an asymmetric body
+    drop_vac, drop_air = c0[2] - c1[2], com["air"][0][2] - com["air"][1][2]
+    assert 0.8 * drop_vac < drop_air < drop_vac                       # inertia-box drag slows the fall
+
+
+def test_k4b_humanoid_ballistic_com(oracle):
+    """Total linear momentum of a free-floating tree changes only by gravity (no contacts, ctrl = 0)."""
+    m, d = oracle("humanoid")
+    cm = m.compiled
+    d.reset()
+    d.qpos[2] += 5.0
+    d.qvel[:3] = [0.3, -0.2, 0.5]
+    d.forward()
+    com0 = d.subtree_com[3:6].copy()
+    n, h = 100, cm.timestep
+    for _ in range(n):
+        d.step()
+    d.forward()
+    t = n * h
+    expect = com0 + np.array([0.3, -0.2, 0.5]) * t + np.array([0, 0, -0.5 * G * t * (t + h)])   # semi-implicit Euler
+    assert d.subtree_com[3:6] == pytest.approx(expect, abs=1e-9)
+
+
+def test_k7_fd_matches_analytic_pendulum_linearisation(oracle):
+    """A from transition_fd ~ d(x')/dx of the RK4 map; compare with a fine analytic reference of the pendulum ODE."""
+    m, d = oracle("pendulum")
+    mass, I, L, h = 0.7941946228, 0.06809102997, 0.25, 0.005
+    th = 0.4
+    d.qpos[0] = th
+    d.qvel[0] = 0.0
+    A, B = d.transition_fd(1e-6, True)
+    k = mass * G * L * math.cos(th) / I                  # theta'' = -k dtheta + u / I
+    Ac = np.array([[0, 1], [-k, 0]])
+    Ad = np.eye(2)
+    term = np.eye(2)
+    for i in range(1, 5):                                # RK4 = 4th-order Taylor of expm(h Ac)
+        term = term @ (h * Ac) / i
+        Ad = Ad + term
+    assert A == pytest.approx(Ad, abs=1e-5)      # frozen-coefficient linearisation: O(h^2) nonlinearity left
+    Bd = np.array([[h * h / 2 / I], [h / I]])
+    assert B == pytest.approx(Bd, rel=1e-3, abs=1e-6)
+    assert d.qpos[0] == pytest.approx(th) and d.time == pytest.approx(0.0)   # state restored
+
+
+def test_k7b_fd_cartpole_matches_analytic_euler_map(oracle):
+    m, d = oracle("cartpole")
+    d.qpos[:] = [0.0, 0.0]
+    A, B = d.transition_fd(1e-6, True)
+    mc, l, h = 4.8, 0.3, 0.01
+    mp, Ip = _pole()
+    M = np.array([[mc + mp, mp * l], [mp * l, Ip + mp * l * l]])
+    D = np.diag([1.0, 0.1])
+    K = np.array([[0, 0], [0, -mp * G * l]])             # d(bias)/dq at the upright... pole up: bias_theta = -m g l sin(th)
+    Minv = np.linalg.inv(M + h * D)
+    dv_dq = -h * Minv @ K
+    dv_dv = np.eye(2) - h * Minv @ D
+    Aexp = np.block([[np.eye(2) + h * dv_dq, h * dv_dv], [dv_dq, dv_dv]])
+    assert A == pytest.approx(Aexp, abs=5e-6)
+    Bexp = np.concatenate([h * h * Minv @ [50.0, 0.0], h * Minv @ [50.0, 0.0]]).reshape(4, 1)
+    assert B == pytest.approx(Bexp, abs=1e-7)
+
+
+def test_k8_resting_sphere_penetration_matches_soft_constraint_law():
+    """Sphere resting on a plane (frictionless, condim 1): at equilibrium the constraint force balances m g
+    and the penetration r solves  D * K * imp(r) * r = m g  with R = (1-imp)/imp * (1/m), D = 1/R."""
+    xml = """<mujoco><option timestep="0.002"/><worldbody><geom type="plane" size="0 0 1" condim="1"/>
+      <body pos="0 0 0.1"><freejoint/><geom type="sphere" size="0.1" density="1000" condim="1"/></body></worldbody></mujoco>"""
+    cm = mjcf.compile_xml_string(xml)
+    om = mjo.OracleModel(cm)
+    d = mjo.OracleData(om)
+    for _ in range(3000):
+        d.step()
+    assert np.abs(d.qvel).max() < 1e-8
+    pen = 0.1 - d.qpos[2]
+    mass = cm.body_mass[1]
+    solref, solimp = (0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)
+    x = min(pen / solimp[2], 1.0)
+    y = 2 * x * x if x <= 0.5 else 1 - 2 * (1 - x) ** 2
+    imp = solimp[0] + y * (solimp[1] - solimp[0])
+    K = 1.0 / (solimp[1] ** 2 * solref[0] ** 2)
+    force = (imp / (1 - imp)) * mass * K * imp * pen     # D * aref with diagApprox = 1/m
+    assert force == pytest.approx(mass * G, rel=1e-6)
+    assert d.counters()["nefc"] == 1
+
+
+def test_integrate_differentiate_roundtrip(oracle):
+    m, d = oracle("humanoid")
+    rng = np.random.default_rng(3)
+    q0 = m.compiled.qpos0.copy()
+    v = rng.normal(size=m.nv) * 0.3
+    q1 = d.integrate_pos(q0, v, 0.7)
+    assert np.linalg.norm(q1[3:7]) == pytest.approx(1.0)
+    back = d.differentiate_pos(q0, q1, 0.7)
+    assert back == pytest.approx(v, abs=1e-12)
+
+
+def test_jacobians_match_finite_differences(oracle):
+    m, d = oracle("humanoid")
+    cm = m.compiled
+    rng = np.random.default_rng(5)
+    q = d.integrate_pos(cm.qpos0, rng.normal(size=m.nv) * 0.2, 1.0)
+    d.qpos[:] = q
+    d.forward()
+    bid = cm.name2id(mjcf.OBJ_BODY, "foot_left")
+    jp, jr = d.jac(1, bid)
+    jc, _ = d.jac(3, 1)                                  # subtree com of the whole tree
+    x0, c0 = d.xpos[3 * bid:3 * bid + 3].copy(), d.subtree_com[3:6].copy()
+    eps = 1e-6
+    for i in range(m.nv):
+        e = np.zeros(m.nv)
+        e[i] = eps
+        d.qpos[:] = d.integrate_pos(q, e, 1.0)
+        d.forward()
+        assert (d.xpos[3 * bid:3 * bid + 3] - x0) / eps == pytest.approx(jp[:, i], abs=2e-5)
+        assert (d.subtree_com[3:6] - c0) / eps == pytest.approx(jc[:, i], abs=2e-5)
+
+
+def test_contact_geometry_plane_primitives():
+    xml = """<mujoco><worldbody><geom name="floor" type="plane" size="0 0 1"/>
+      <body pos="0 0 0.09"><freejoint/><geom type="sphere" size="0.1" contype="0"/></body>
+      <body pos="1 0 0.04"><freejoint/><geom type="capsule" size="0.05 0.2" quat="0.7071068 0 0.7071068 0" contype="0"/></body>
+      <body pos="2 0 0.045"><freejoint/><geom type="box" size="0.1 0.2 0.05" contype="0"/></body>
+      <body pos="3 0 0.02"><freejoint/><geom type="ellipsoid" size="0.1 0.2 0.03" contype="0"/></body>
+      </worldbody></mujoco>"""
+    cm = mjcf.compile_xml_string(xml)
+    d = mjo.OracleData(mjo.OracleModel(cm))
+    d.forward()
+    con = d.contacts()
+    assert len(con["dist"]) == 1 + 2 + 4 + 1
+    assert con["dist"] == pytest.approx([-0.01, -0.01, -0.01, -0.005, -0.005, -0.005, -0.005, -0.01], abs=1e-9)
+    assert np.allclose(con["frame"][:, 0, :], [0, 0, 1])            # normals point from the plane (geom1) to geom2
+    for f in con["frame"]:
+        assert f @ f.T == pytest.approx(np.eye(3), abs=1e-12) and np.linalg.det(f) == pytest.approx(1.0)
+    assert con["pos"][0] == pytest.approx([0, 0, -0.005])           # midway between the surfaces
+    assert sorted(np.round(con["pos"][1:3, 0], 6)) == [0.8, 1.2]    # capsule end points
+    assert d.counters()["nefc"] == 8 * 4                            # condim 3 -> 4 pyramid edges per contact
+
+
+def test_solver_reaches_kkt_on_humanoid(oracle):
+    """At the solution of the primal problem the gradient M(a - a_smooth) - J^T f vanishes."""
+    m, d = oracle("humanoid")
+    d.reset()
+    d.forward()
+    c = d.counters()
+    assert c["nefc"] == 32 and c["ncon"] == 8
+    nv = m.nv
+    M = d.qM.reshape(nv, nv)
+    J = d.efc_J.reshape(-1, nv)
+    f = d.efc_force
+    assert (f >= 0).all()
+    grad = M @ (d.qacc - d.qacc_smooth) - J.T @ f
+    assert np.abs(grad).max() < 1e-6
+    assert d.qfrc_constraint == pytest.approx(J.T @ f, abs=1e-9)
+    jar = J @ d.qacc - d.efc_aref
+    assert f == pytest.approx(np.where(jar < 0, -d.efc_D * jar, 0.0), abs=1e-9)
