@@ -125,9 +125,10 @@ def test_gloo_world_size_2_all_gather_obs(tmp_path):
         "e0, c = shard_range(9, rank, ws)                      # ragged shards: 5 + 4\n"
         "out = all_gather_obs(full[:, e0:e0 + c].clone())\n"
         "assert torch.equal(out, full[:, :9])\n"
-        "dist.barrier(); dist.destroy_process_group(); print('rank', rank, 'ok')\n")
+        "dist.barrier(); dist.destroy_process_group()\n"
+        f"open(os.path.join({str(tmp_path)!r}, 'ok_%d' % rank), 'w').write('ok')\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29611", str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
