@@ -216,8 +216,9 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
   if (lanes != 8 && lanes != 16 && lanes != 64) return fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64");
   mjbData* d = new mjbData();
   d->model = m; d->batch = batch; d->dtype = dtype; d->G = lanes; d->device = device; d->env0 = env0; d->stream = nullptr;
-  d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 48 ? h.ncon_alloc : 48);
-  d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 128 ? h.nefc_alloc : 128);
+  // default caps: 32 contacts / 96 rows per environment (humanoid worst case seen: 13 contacts, 54 rows); drops are counted
+  d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 32 ? h.ncon_alloc : 32);
+  d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 96 ? h.nefc_alloc : 96);
   if (d->ncon_max < 1) d->ncon_max = 1;
   if (d->nefc_max < 1) d->nefc_max = 1;
   fill_dev_model<float>(h, d->alloc, d->ncon_max, d->nefc_max, d->mf);
@@ -337,7 +338,7 @@ static StepArgs make_args(mjbData* d, int nstep, int ctrl_mode, unsigned seed, u
   StepArgs a;
   std::memset(&a, 0, sizeof(a));
   a.nstep = nstep; a.ctrl_mode = ctrl_mode; a.seed = seed; a.step0 = step0; a.env0 = (unsigned)d->env0;
-  a.ctrl_scale = (float)scale; a.mode = mode; a.write_kin = 1; a.obs_every = 0;
+  a.ctrl_scale = scale; a.dt = d->model->h.timestep; a.mode = mode; a.write_kin = 1; a.obs_every = 0;
   return a;
 }
 

@@ -1409,7 +1409,7 @@ MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, c
     }
     if (a.mode == 1) break;
     if (nstage == 1) euler<T, G>(c);
-    time += (double)m.timestep;
+    time += a.dt;
     if (a.obs_every > 0 && ((s + 1) % a.obs_every) == 0) {
       size_t slot = (size_t)((s + 1) / a.obs_every - 1);
       write_obs<T, TS, G>(c, obs, time, obs_out + (slot * (size_t)d.batch + (size_t)env) * (size_t)obs.dim);

@@ -107,7 +107,8 @@ struct StepArgs {
   int nstep;
   int ctrl_mode;         // CTRL_*
   unsigned seed, step0, env0;   // env0 = global index of this shard's first env (RNG is shard-invariant)
-  float ctrl_scale;
+  double ctrl_scale;     // random-ctrl amplitude as a fraction of the ctrl half-range
+  double dt;             // model timestep in float64 (time is accumulated in double whatever the state dtype)
   int mode;              // 0 = step, 1 = forward only
   int write_kin;         // write xpos/xipos/site_xpos/geom_xpos/subtree_com/sensordata of the last forward pass
   int obs_every;         // >0: write flat obs every k steps into obs_out[(step/k), env, dim]

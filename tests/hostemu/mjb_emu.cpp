@@ -90,7 +90,7 @@ int mjbemu_run(int nfield, const char* const* names, const void* const* ptrs, co
   dbg.cdof = (double*)io("cdof"); dbg.cinert = (double*)io("cinert"); dbg.cvel = (double*)io("cvel");
   StepArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.nstep = nstep; a.ctrl_mode = ctrl_mode; a.seed = seed; a.step0 = step0; a.env0 = env0; a.ctrl_scale = scale; a.mode = mode;
+  a.nstep = nstep; a.ctrl_mode = ctrl_mode; a.seed = seed; a.step0 = step0; a.env0 = env0; a.ctrl_scale = scale; a.dt = h.timestep; a.mode = mode;
   a.write_kin = d.xpos != nullptr; a.obs_every = 0;
   ObsSpecDev obs;
   std::memset(&obs, 0, sizeof(obs));

@@ -40,13 +40,13 @@ def test_model_handle_rejects_mismatched_data():
 
 
 def test_host_edits_reach_the_device(handle):
-    handle.data.qpos[0] = 0.3                    # in-place edit of the mirror, as reference controllers do in prepare()
+    handle.data.qpos[0] = 0.005                  # in-place edit of the mirror, as reference controllers do in prepare()
     handle.forward()
     assert handle.data.site_xpos[0] == pytest.approx([0, 0, 0.2])
-    assert handle.data.sensordata[0] == pytest.approx(0.3, abs=1e-6)     # jointpos sensor follows the edit
+    assert handle.data.sensordata[0] == pytest.approx(0.005, abs=1e-7)   # jointpos sensor follows the edit
     handle.data.qvel[:] = 1.0
     handle.step()
-    assert handle.data.qpos[0] > 0.3
+    assert handle.data.qpos[0] == pytest.approx(0.005 + 0.005 * 1.0, abs=2e-4)   # inside the +-1 degree range: free motion
 
 
 def test_env_step_can_skip_observation_and_hooks(handle):
