@@ -120,6 +120,12 @@ def main() -> None:
         avg_steps = float(np.mean(steps_per_launch))
         launch_bytes = count * (bytes_step * avg_steps + bytes_obs)          # one obs row per env per launch
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None          # HBM bytes per launch from the committed PMC profile of this same command (separate --pmc passes)
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            rec = json.load(open(prof))
+            if rec.get("global_batch") == global_batch and rec.get("chunk") == args.chunk and ws == 1 and args.model == rec.get("model"):
+                traffic = rec.get("traffic_bytes_per_launch")
         out = {
             "metric": "env-steps/sec (whole node), humanoid batch=4096 random-ctrl rollout" if args.model == "humanoid"
                       else f"env-steps/sec (whole node), {args.model} random-ctrl rollout",
@@ -142,7 +148,7 @@ def main() -> None:
                        "lanes_per_env": sim.lanes, "lds_bytes_per_env": sim.lds_bytes_per_env,
                        "nefcmax": sim.nefcmax, "nconmax": sim.nconmax},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mjb::k_step<float,float,%d>" % sim.lanes,
+                         "traffic": traffic, "kernel": "mjb::k_step<float,float,%d>" % sim.lanes,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_env_step": bytes_step, "obs_bytes_per_env": bytes_obs,
                          "note": "fused step is VALU/LDS-latency bound by construction (SURVEY.md §8d); see DESIGN.md for VALU/LDS counters"},
             "solver": {"mean_nefc_last_step": float(counters["nefc"].mean()), "max_nefc_last_step": int(counters["nefc"].max()),
