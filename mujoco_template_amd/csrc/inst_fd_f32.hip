@@ -2,13 +2,13 @@
 #include "mjb_kernels.hpp"
 namespace mjb {
 template <>
-hipError_t launch_fd<double, float>(int G, const DevModel<double>& m, const Lay& L, const DevData<float>& d, int ncol, double eps, double* y, int* valid, hipStream_t stream) {
-  MJB_DISPATCH_G(G, return (launch_fd_g<double, float, GG>(m, L, d, ncol, eps, y, valid, stream)));
+hipError_t launch_fd<double, float>(int G, const DevModel<double>* m, const Lay* Ldev, const Lay& L, const DevData<float>& d, int ncol, double eps, double* y, int* valid, hipStream_t stream) {
+  MJB_DISPATCH_G(G, return (launch_fd_g<double, float, GG>(m, Ldev, L, d, ncol, eps, y, valid, stream)));
   return hipErrorInvalidValue;
 }
 template <>
-hipError_t launch_jac<double, float>(int G, const DevModel<double>& m, const Lay& L, const DevData<float>& d, int nreq, const int* kinds, const int* ids, double* out_p, double* out_r, hipStream_t stream) {
-  MJB_DISPATCH_G(G, return (launch_jac_g<double, float, GG>(m, L, d, nreq, kinds, ids, out_p, out_r, stream)));
+hipError_t launch_jac<double, float>(int G, const DevModel<double>* m, const Lay* Ldev, const Lay& L, const DevData<float>& d, int nreq, const int* kinds, const int* ids, double* out_p, double* out_r, hipStream_t stream) {
+  MJB_DISPATCH_G(G, return (launch_jac_g<double, float, GG>(m, Ldev, L, d, nreq, kinds, ids, out_p, out_r, stream)));
   return hipErrorInvalidValue;
 }
 }  // namespace mjb

@@ -2,9 +2,9 @@
 #include "mjb_kernels.hpp"
 namespace mjb {
 template <>
-hipError_t launch_step<float, float>(int G, const DevModel<float>& m, const Lay& L, const DevData<float>& d, const DevDebug<float>& dbg,
+hipError_t launch_step<float, float>(int G, const DevModel<float>* m, const Lay* Ldev, const Lay& L, const DevData<float>& d, const DevDebug<float>& dbg,
                                      const StepArgs& a, const ObsSpecDev& obs, float* obs_out, hipStream_t stream) {
-  MJB_DISPATCH_G(G, return (launch_step_g<float, float, GG>(m, L, d, dbg, a, obs, obs_out, stream)));
+  MJB_DISPATCH_G(G, return (launch_step_g<float, float, GG>(m, Ldev, L, d, dbg, a, obs, obs_out, stream)));
   return hipErrorInvalidValue;
 }
 }  // namespace mjb

@@ -65,6 +65,10 @@ struct mjbData {
   DevModel<float> mf;
   DevModel<double> md;
   Lay Lf, Ld;
+  DevModel<float>* mf_dev = nullptr;    // device copies of the structs above (read through the constant address space)
+  DevModel<double>* md_dev = nullptr;
+  Lay *Lf_dev = nullptr, *Ld_dev = nullptr;
+  int up_disable = -1, up_iter = -1; double up_tol = -1;
   DevData<float> df;
   DevData<double> dd;
   std::map<std::string, ArrayInfo> arrays;
@@ -133,23 +137,31 @@ template <typename TS> int alloc_debug(mjbData* d, DevDebug<TS>& g) {
   return 0;
 }
 
-void refresh_options(mjbData* d) {
-  d->mf.disableactuator = d->md.disableactuator = d->model->disableactuator;
-  d->mf.iterations = d->md.iterations = d->model->iterations;
-  d->md.tolerance = d->model->tolerance;
-  float tol = (float)d->model->tolerance;
+int refresh_options(mjbData* d) {
+  const mjbModel* mm = d->model;
+  if (d->up_disable == mm->disableactuator && d->up_iter == mm->iterations && d->up_tol == mm->tolerance) return MJB_OK;
+  d->mf.disableactuator = d->md.disableactuator = mm->disableactuator;
+  d->mf.iterations = d->md.iterations = mm->iterations;
+  d->md.tolerance = mm->tolerance;
+  float tol = (float)mm->tolerance;
   d->mf.tolerance = tol < 1e-6f ? 1e-6f : tol;
+  HIPCHK(hipStreamSynchronize(d->stream));
+  HIPCHK(hipMemcpy(d->mf_dev, &d->mf, sizeof(d->mf), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d->md_dev, &d->md, sizeof(d->md), hipMemcpyHostToDevice));
+  d->up_disable = mm->disableactuator; d->up_iter = mm->iterations; d->up_tol = mm->tolerance;
+  return MJB_OK;
 }
 
 int launch(mjbData* d, const StepArgs& a, const ObsSpecDev& obs, void* obs_out, bool debug) {
-  refresh_options(d);
+  int rc = refresh_options(d);
+  if (rc != MJB_OK) return rc;
   hipError_t e;
   if (d->dtype == MJB_F32) {
     DevDebug<float> none; std::memset(&none, 0, sizeof(none));
-    e = launch_step<float, float>(d->G, d->mf, d->Lf, d->df, debug ? d->dbgf : none, a, obs, (float*)obs_out, d->stream);
+    e = launch_step<float, float>(d->G, d->mf_dev, d->Lf_dev, d->Lf, d->df, debug ? d->dbgf : none, a, obs, (float*)obs_out, d->stream);
   } else {
     DevDebug<double> none; std::memset(&none, 0, sizeof(none));
-    e = launch_step<double, double>(d->G, d->md, d->Ld, d->dd, debug ? d->dbgd : none, a, obs, (double*)obs_out, d->stream);
+    e = launch_step<double, double>(d->G, d->md_dev, d->Ld_dev, d->Ld, d->dd, debug ? d->dbgd : none, a, obs, (double*)obs_out, d->stream);
   }
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
   return MJB_OK;
@@ -235,6 +247,12 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
     std::snprintf(buf, sizeof buf, "per-workgroup LDS %zu B exceeds 160 KiB (lower nconmax/nefcmax or use more lanes)", lds);
     mjb_data_free(d);
     return fail(MJB_ERR_ARG, buf);
+  }
+  if (dev_alloc(d, &d->mf_dev, 1) || dev_alloc(d, &d->md_dev, 1) || dev_alloc(d, &d->Lf_dev, 1) || dev_alloc(d, &d->Ld_dev, 1) ||
+      hipMemcpy(d->Lf_dev, &d->Lf, sizeof(Lay), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d->Ld_dev, &d->Ld, sizeof(Lay), hipMemcpyHostToDevice) != hipSuccess) {
+    mjb_data_free(d);
+    return fail(MJB_ERR_DEVICE, "device allocation of the model descriptors failed");
   }
   std::memset(&d->df, 0, sizeof(d->df)); std::memset(&d->dd, 0, sizeof(d->dd));
   int rc = dtype == MJB_F32 ? alloc_state(d, d->df) : alloc_state(d, d->dd);
@@ -425,7 +443,7 @@ int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, doub
   if (!(eps > 0)) return fail(MJB_ERR_ARG, "eps must be > 0");
   const HostModel& h = d->model->h;
   HIPCHK(hipSetDevice(d->device));
-  refresh_options(d);
+  { int rc0 = refresh_options(d); if (rc0 != MJB_OK) return rc0; }
   const int nin = 2 * h.nv + h.nu, ncol = 1 + 2 * nin, nx = 2 * h.nv;
   size_t B = (size_t)d->batch;
   if (!d->fd_y) {
@@ -433,11 +451,11 @@ int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, doub
         dev_alloc(d, &d->fd_A, B * nx * nx) || dev_alloc(d, &d->fd_B, B * nx * (h.nu > 0 ? h.nu : 1)))
       return fail(MJB_ERR_DEVICE, "device allocation of FD scratch failed");
   }
-  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md, d->Ld, d->df, ncol, eps, d->fd_y, d->fd_valid, d->stream)
-                                     : launch_fd<double, double>(d->G_fd, d->md, d->Ld, d->dd, ncol, eps, d->fd_y, d->fd_valid, d->stream);
+  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, ncol, eps, d->fd_y, d->fd_valid, d->stream)
+                                     : launch_fd<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, ncol, eps, d->fd_y, d->fd_valid, d->stream);
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("fd launch: ") + hipGetErrorString(e));
   long nthreads = (long)B * nin;
-  hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, d->md, d->batch, ncol, centered, eps,
+  hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, (const DevModel<double>*)d->md_dev, d->batch, ncol, centered, eps,
                      (const double*)d->fd_y, (const int*)d->fd_valid, d->fd_A, d->fd_B);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(d->stream));
@@ -455,6 +473,7 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
     if (ids[i] < 0 || ids[i] >= lim) return fail(MJB_ERR_LOOKUP, "jacobian object id out of range");
   }
   HIPCHK(hipSetDevice(d->device));
+  { int rc0 = refresh_options(d); if (rc0 != MJB_OK) return rc0; }
   size_t n = (size_t)d->batch * nreq * 3 * h.nv;
   double *op = nullptr, *orr = nullptr; int *dk = nullptr, *di = nullptr;
   HIPCHK(hipMalloc((void**)&op, sizeof(double) * (n ? n : 1)));
@@ -463,8 +482,8 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
   HIPCHK(hipMalloc((void**)&di, sizeof(int) * nreq));
   HIPCHK(hipMemcpy(dk, kinds, sizeof(int) * nreq, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(di, ids, sizeof(int) * nreq, hipMemcpyHostToDevice));
-  hipError_t e = d->dtype == MJB_F32 ? launch_jac<double, float>(d->G_fd, d->md, d->Ld, d->df, nreq, dk, di, op, orr, d->stream)
-                                     : launch_jac<double, double>(d->G_fd, d->md, d->Ld, d->dd, nreq, dk, di, op, orr, d->stream);
+  hipError_t e = d->dtype == MJB_F32 ? launch_jac<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, nreq, dk, di, op, orr, d->stream)
+                                     : launch_jac<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, nreq, dk, di, op, orr, d->stream);
   int rc = MJB_OK;
   if (e != hipSuccess) rc = fail(MJB_ERR_DEVICE, std::string("jac launch: ") + hipGetErrorString(e));
   if (rc == MJB_OK && hipStreamSynchronize(d->stream) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac sync failed");

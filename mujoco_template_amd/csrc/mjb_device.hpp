@@ -36,14 +36,45 @@ namespace mjb {
 // ---------------------------------------------------------------------------
 #ifndef MJB_HOST_EMU
 template <int G> MJB_DEV void gsync() { __syncthreads(); }   // block == one wavefront: lowers to a wave barrier
+
+// DPP lane permutations inside a 16-lane row (no LDS traffic): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E,
+// row_half_mirror = 0x141, row_mirror = 0x140.  After the four steps every lane of a row holds the row total.
+template <int CTRL> MJB_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> MJB_DEV float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL> MJB_DEV double dpp_f(double v) {
+  return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+MJB_DEV int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+MJB_DEV float rdlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+MJB_DEV double rdlane_f(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 template <typename T, int G> MJB_DEV T gsum(T v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  if (G >= 8) v += dpp_f<0x141>(v);
+  if (G >= 16) v += dpp_f<0x140>(v);
+  if (G == 64) v = (rdlane_f(v, 0) + rdlane_f(v, 16)) + (rdlane_f(v, 32) + rdlane_f(v, 48));
   return v;
 }
 template <int G> MJB_DEV int gsumi(int v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  v += dpp_i<0xB1>(v);
+  v += dpp_i<0x4E>(v);
+  if (G >= 8) v += dpp_i<0x141>(v);
+  if (G >= 16) v += dpp_i<0x140>(v);
+  if (G == 64) v = (rdlane_i(v, 0) + rdlane_i(v, 16)) + (rdlane_i(v, 32) + rdlane_i(v, 48));
+  return v;
+}
+template <int G> MJB_DEV int gmaxi(int v) {
+  int t;
+  t = dpp_i<0xB1>(v); v = t > v ? t : v;
+  t = dpp_i<0x4E>(v); v = t > v ? t : v;
+  if (G >= 8) { t = dpp_i<0x141>(v); v = t > v ? t : v; }
+  if (G >= 16) { t = dpp_i<0x140>(v); v = t > v ? t : v; }
+  if (G == 64) {
+    int a0 = rdlane_i(v, 0), a1 = rdlane_i(v, 16), a2 = rdlane_i(v, 32), a3 = rdlane_i(v, 48);
+    a0 = a0 > a1 ? a0 : a1; a2 = a2 > a3 ? a2 : a3; v = a0 > a2 ? a0 : a2;
+  }
   return v;
 }
 template <int G> MJB_DEV int gscan_excl(int v, int lane, int& total) {
@@ -53,11 +84,10 @@ template <int G> MJB_DEV int gscan_excl(int v, int lane, int& total) {
   total = __shfl(x, G - 1, G);
   return x - v;
 }
-template <typename T, int G> MJB_DEV T gshfl(T v, int src) { return __shfl(v, src, G); }
-template <int G> MJB_DEV int gmaxi(int v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) { int y = __shfl_xor(v, o, G); v = y > v ? y : v; }
-  return v;
+// value of lane `src` of the group; src must be group-uniform.  One wavefront per environment: v_readlane (no LDS hop).
+template <typename T, int G> MJB_DEV T gshfl(T v, int src) {
+  if (G == 64) return rdlane_f(v, __builtin_amdgcn_readfirstlane(src));
+  return __shfl(v, src, G);
 }
 #endif
 
@@ -262,21 +292,35 @@ template <typename T, int G> MJB_DEV void chol_solve(const T* L, const T* dinv, 
 // ---------------------------------------------------------------------------
 // environment context: LDS slice + model, passed to every phase
 // ---------------------------------------------------------------------------
+// Re-materialise the model / layout pointers at the start of every phase: the (invariant) loads through
+// them then stay local to the phase instead of being hoisted to the kernel entry, where ~190 live SGPRs
+// were spilled to VGPR lanes (17 % of the instruction stream was v_readlane / v_writelane).
+#ifdef MJB_HOST_EMU
+#define MJB_ENV(c) ModelRef<T> m = *(c).mp; LayRef L = *(c).lp
+#else
+#define MJB_ENV(c)                                     \
+  auto mp_ = (c).mp; auto lp_ = (c).lp;                \
+  asm volatile("" : "+s"(mp_), "+s"(lp_));             \
+  ModelRef<T> m = *mp_; LayRef L = *lp_
+#endif
+template <typename T> using ModelRef = const DevModel<T> MJB_CONST&;
+typedef const Lay MJB_CONST& LayRef;
+
 template <typename T> struct Ctx {
-  const DevModel<T>& m;
-  const Lay& L;
+  const DevModel<T> MJB_CONST* mp;
+  const Lay MJB_CONST* lp;
   T* w;      // T region of this environment's LDS slice
   int* wi;   // int region
   int lane;
   int ncon, nefc, niter, con_dropped, efc_dropped;
-  MJB_DEVM Ctx(const DevModel<T>& m_, const Lay& L_, T* w_, int* wi_, int lane_) : m(m_), L(L_), w(w_), wi(wi_), lane(lane_), ncon(0), nefc(0), niter(0), con_dropped(0), efc_dropped(0) {}
+  MJB_DEVM Ctx(const DevModel<T> MJB_CONST* m_, const Lay MJB_CONST* L_, T* w_, int* wi_, int lane_) : mp(m_), lp(L_), w(w_), wi(wi_), lane(lane_), ncon(0), nefc(0), niter(0), con_dropped(0), efc_dropped(0) {}
 };
 
 // ---------------------------------------------------------------------------
 // A1 kinematics: tree levels in order, bodies of a level across lanes
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane;
   T *xpos = w + L.xpos, *xquat = w + L.xquat, *xmat = w + L.xmat, *xipos = w + L.xipos, *ximat = w + L.ximat;
   T *qpos = w + L.qpos, *xanchor = w + L.xanchor, *xaxis = w + L.xaxis;
   if (lane == 0) {
@@ -357,8 +401,8 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
     bool is_geom = g < m.ngeom;
     int id = is_geom ? g : g - m.ngeom;
     int b = is_geom ? m.geom_bodyid[id] : m.site_bodyid[id];
-    const T* lp = is_geom ? m.geom_pos + 3 * id : m.site_pos + 3 * id;
-    const T* lq = is_geom ? m.geom_quat + 4 * id : m.site_quat + 4 * id;
+    auto lp = is_geom ? m.geom_pos + 3 * id : m.site_pos + 3 * id;
+    auto lq = is_geom ? m.geom_quat + 4 * id : m.site_quat + 4 * id;
     T p3[3] = {lp[0], lp[1], lp[2]}, q4[4] = {lq[0], lq[1], lq[2], lq[3]}, bm[9], bq[4], t[3], q[4], R[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) bm[k] = xmat[9 * b + k];
@@ -382,7 +426,7 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
 // A2 com-frame quantities: subtree_com, cinert, cdof
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane;
   T *sc = w + L.subtree_com, *xipos = w + L.xipos, *ximat = w + L.ximat, *xmat = w + L.xmat;
   for (int b = lane; b < m.nbody; b += G) {
     T ms = m.body_mass[b];
@@ -468,12 +512,12 @@ template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
 
 // Jacobian column of dof i for a world point attached to body b (zero if i does not move b)
 template <typename T> MJB_DEV void jac_col(const Ctx<T>& c, int b, int i, const T* point, T* jp, T* jr) {
-  const DevModel<T>& m = c.m;
+  ModelRef<T> m = *c.mp;
   jp[0] = jp[1] = jp[2] = 0;
   if (jr) { jr[0] = jr[1] = jr[2] = 0; }
   if (!((m.body_dofmask[b] >> i) & 1ull)) return;
-  const T* cd = c.w + c.L.cdof + 6 * i;
-  const T* sc = c.w + c.L.subtree_com + 3 * m.body_rootid[b];
+  const T* cd = c.w + c.lp->cdof + 6 * i;
+  const T* sc = c.w + c.lp->subtree_com + 3 * m.body_rootid[b];
   T off[3] = {point[0] - sc[0], point[1] - sc[1], point[2] - sc[2]}, ang[3] = {cd[0], cd[1], cd[2]}, t[3];
   cross3(t, ang, off);
   jp[0] = cd[3] + t[0]; jp[1] = cd[4] + t[1]; jp[2] = cd[5] + t[2];
@@ -484,7 +528,7 @@ template <typename T> MJB_DEV void jac_col(const Ctx<T>& c, int b, int i, const 
 // A4 composite rigid body -> dense M in LDS, Cholesky factor in W
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv;
   T *crb = w + L.crb, *cin = w + L.cinert, *cdof = w + L.cdof, *buf = w + L.dofbuf, *M = w + L.M, *W = w + L.W;
   for (int i = lane; i < 10 * m.nbody; i += G) crb[i] = cin[i];
   gsync<G>();
@@ -560,7 +604,7 @@ template <typename T> MJB_DEV int nc_plane_sphere(const T* pp, const T* n, const
 }
 
 template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane;
   T *gx = w + L.geom_xpos, *gm = w + L.geom_xmat, *con = w + L.con;
   int* con_pair = c.wi + L.i_con_pair;
   int ncon = 0, dropped = 0;
@@ -697,7 +741,7 @@ template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
 // ---------------------------------------------------------------------------
 // A6 constraint rows: limits + contacts; impedance, R/D, Jacobian, aref
 // ---------------------------------------------------------------------------
-template <typename T> MJB_DEV void row_params(const DevModel<T>& m, T pos, T margin, const T* solref, const T* solimp, T diagApprox, T& K, T& B, T& imp, T& R) {
+template <typename T> MJB_DEV void row_params(ModelRef<T> m, T pos, T margin, const T* solref, const T* solimp, T diagApprox, T& K, T& B, T& imp, T& R) {
   T dmin = t_min(t_max(solimp[0], MJB_MINIMP), MJB_MAXIMP), dmax = t_min(t_max(solimp[1], MJB_MINIMP), MJB_MAXIMP);
   T width = t_max(solimp[2], (T)0), mid = t_min(t_max(solimp[3], MJB_MINIMP), MJB_MAXIMP), power = t_max(solimp[4], (T)1);
   if (dmin == dmax || width <= Num<T>::minval()) imp = (T)0.5 * (dmin + dmax);
@@ -726,7 +770,7 @@ template <typename T> MJB_DEV void row_params(const DevModel<T>& m, T pos, T mar
 }
 
 template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, cap = m.nefc_max;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, cap = m.nefc_max;
   T *qpos = w + L.qpos, *qvel = w + L.qvel, *J = w + L.efc_J, *epos = w + L.efc_pos, *eD = w + L.efc_D, *earef = w + L.efc_aref;
   T *eK = w + L.efc_jar, *eB = w + L.efc_jv, *eI = w + L.efc_force;       // K, B, imp scratch until aref is known
   T *emargin = w + L.efc_KBI;
@@ -744,7 +788,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
         bool lim = pass == 0 ? (m.jnt_limited[o] && (m.jnt_type[o] == JNT_HINGE || m.jnt_type[o] == JNT_SLIDE)) : (m.tendon_limited[o] != 0);
         if (lim) {
           T value = pass == 0 ? qpos[m.jnt_qposadr[o]] : tl[o];
-          const T* rng = pass == 0 ? m.jnt_range + 2 * o : m.tendon_range + 2 * o;
+          auto rng = pass == 0 ? m.jnt_range + 2 * o : m.tendon_range + 2 * o;
           margin = pass == 0 ? m.jnt_margin[o] : m.tendon_margin[o];
           dist[0] = value - rng[0]; dist[1] = rng[1] - value;
           act[0] = dist[0] < margin; act[1] = dist[1] < margin;
@@ -757,8 +801,8 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
       for (int s = 0; s < 2; s++) {
         if (act[s]) {
           if (row < cap) {
-            const T* solref = pass == 0 ? m.jnt_solref + 2 * o : m.tendon_solref + 2 * o;
-            const T* solimp = pass == 0 ? m.jnt_solimp + 5 * o : m.tendon_solimp + 5 * o;
+            auto solref = pass == 0 ? m.jnt_solref + 2 * o : m.tendon_solref + 2 * o;
+            auto solimp = pass == 0 ? m.jnt_solimp + 5 * o : m.tendon_solimp + 5 * o;
             T sr[2] = {solref[0], solref[1]}, si[5] = {solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
             T diag = pass == 0 ? m.dof_invweight0[m.jnt_dofadr[o]] : m.tendon_invweight0[o];
             T K, B, imp, R;
@@ -878,7 +922,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
 // A7 velocity stage: cvel, cdof_dot, bias forces (RNE), passive forces
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv;
   T *cvel = w + L.cvel, *cacc = w + L.cacc, *cfrc = w + L.cfrc, *cdof = w + L.cdof, *cdd = w + L.cdof_dot, *cin = w + L.cinert;
   T *qvel = w + L.qvel, *qpos = w + L.qpos;
   if (lane == 0) {
@@ -1028,7 +1072,7 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
 // A8/A9 actuation and unconstrained acceleration
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv;
   T *ctrl = w + L.ctrl, *af = w + L.act_force, *qpos = w + L.qpos, *qvel = w + L.qvel;
   for (int a = lane; a < m.nu; a += G) {
     int grp = m.actuator_group[a];
@@ -1086,7 +1130,7 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, bool store) {
   // Ma = M qacc, jar = J qacc - aref; returns Gauss + constraint cost.  store=false leaves force untouched.
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
   T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *aref = w + L.efc_aref, *D = w + L.efc_D, *force = w + L.efc_force;
   T *qs = w + L.qfrc_smooth, *qas = w + L.qacc_smooth;
   T part = 0;
@@ -1108,12 +1152,20 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   return cost;
 }
 
-template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c) {
-  // grad, H = M + J^T D_active J (lower, into W), search = -H^-1 grad.  Returns |grad|^2.
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first) {
+  // grad, H = M + J^T D_active J (lower, Cholesky in W), search = -H^-1 grad.  Returns |grad|^2.
+  // The factor is rebuilt only when the active set changed since the last build (bit 8 of efc_type remembers it).
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
   T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *D = w + L.efc_D, *force = w + L.efc_force;
   T *grad = w + L.grad, *search = w + L.search, *qs = w + L.qfrc_smooth, *dw = w + L.efc_jv;
-  for (int r = lane; r < nefc; r += G) dw[r] = jar[r] < 0 ? D[r] : (T)0;
+  int* etype = c.wi + L.i_efc_type;
+  int chg = first ? 1 : 0;
+  for (int r = lane; r < nefc; r += G) {
+    int act = jar[r] < 0 ? 1 : 0, t = etype[r];
+    if (((t >> 8) & 1) != act) chg = 1;
+    etype[r] = (t & 0xff) | (act << 8);
+    dw[r] = act ? D[r] : (T)0;
+  }
   T gpart = 0;
   for (int i = lane; i < nv; i += G) {
     T g = Ma[i] - qs[i];
@@ -1122,20 +1174,23 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c) {
     gpart += g * g;
   }
   T gn = gsum<T, G>(gpart);
+  const bool rebuild = gsumi<G>(chg) != 0;
   gsync<G>();
-  int np = nv * (nv + 1) / 2;
-  for (int idx = lane; idx < np; idx += G) {
-    int i, k;
-    tri_rc(m.tri_tab, idx, i, k);
-    T h = M[i * nv + k];
-    for (int r = 0; r < nefc; r++) {
-      T d = dw[r];
-      if (d != 0) h += d * J[r * nv + i] * J[r * nv + k];
+  if (rebuild) {
+    int np = nv * (nv + 1) / 2;
+    for (int idx = lane; idx < np; idx += G) {
+      int i, k;
+      tri_rc(m.tri_tab, idx, i, k);
+      T h = M[i * nv + k];
+      for (int r = 0; r < nefc; r++) {
+        T d = dw[r];
+        if (d != 0) h += d * J[r * nv + i] * J[r * nv + k];
+      }
+      W[i * nv + k] = h;
     }
-    W[i * nv + k] = h;
+    gsync<G>();
+    chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
   }
-  gsync<G>();
-  chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
   chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
   for (int i = lane; i < nv; i += G) search[i] = -search[i];
   gsync<G>();
@@ -1143,7 +1198,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c) {
 }
 
 template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
   T *qacc = w + L.qacc, *ws = w + L.qacc_ws, *qas = w + L.qacc_smooth, *qc = w + L.qfrc_constraint;
   c.niter = 0;
   if (nefc == 0) {
@@ -1167,7 +1222,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   gsync<G>();
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
   for (int iter = 0; iter < m.iterations; iter++) {
-    T gn = newton_direction<T, G>(c);
+    T gn = newton_direction<T, G>(c, iter == 0);
     if (scale * t_sqrt(gn) < m.tolerance) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
@@ -1243,7 +1298,7 @@ template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
 }
 
 // A16 position integration for the joints of one environment (lanes over joints)
-template <typename T, int G> MJB_DEV void integrate_pos(const DevModel<T>& m, T* qpos, const T* qvel, T h, int lane) {
+template <typename T, int G> MJB_DEV void integrate_pos(ModelRef<T> m, T* qpos, const T* qvel, T h, int lane) {
   for (int j = lane; j < m.njnt; j += G) {
     int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
     if (m.jnt_type[j] == JNT_FREE) {
@@ -1257,7 +1312,7 @@ template <typename T, int G> MJB_DEV void integrate_pos(const DevModel<T>& m, T*
 
 // A11 Euler with implicit joint damping (mj_Euler)
 template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv;
   T *qacc = w + L.qacc, *qvel = w + L.qvel, *qpos = w + L.qpos, *tmpv = w + L.Mv, *M = w + L.M, *W = w + L.W;
   T h = m.timestep;
   if (m.has_damping) {
@@ -1285,7 +1340,7 @@ template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
 // A11 RK4 (mj_RungeKutta, N = 4) as a stage machine so that forward() has a single call site.
 // rk scratch: X0q[nq] X0v[nv] Fv[4nv] Fa[4nv] dv[nv].  Call after the forward pass of stage st (0..3).
 template <typename T, int G> MJB_DEV void rk4_stage(Ctx<T>& c, int st) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w; const int lane = c.lane, nv = m.nv, nq = m.nq;
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nq = m.nq;
   T *qacc = w + L.qacc, *qvel = w + L.qvel, *qpos = w + L.qpos;
   T *X0q = w + L.rk, *X0v = X0q + nq, *Fv = X0v + nv, *Fa = Fv + 4 * nv, *dv = Fa + 4 * nv;
   const T h = m.timestep;
@@ -1323,7 +1378,7 @@ MJB_DEV unsigned philox_first(unsigned c0, unsigned c1, unsigned c2, unsigned c3
   }
   return c0;
 }
-template <typename T, int G> MJB_DEV void random_ctrl(const DevModel<T>& m, T* ctrl, unsigned seed, unsigned env, unsigned step, T scale, int lane) {
+template <typename T, int G> MJB_DEV void random_ctrl(ModelRef<T> m, T* ctrl, unsigned seed, unsigned env, unsigned step, T scale, int lane) {
   for (int a = lane; a < m.nu; a += G) {
     unsigned r = philox_first(env, step, (unsigned)a, 0u, seed, 0x5EEDu);
     T u = (T)(r >> 8) * (T)(1.0 / 16777216.0);
@@ -1340,7 +1395,7 @@ template <typename T, int G> MJB_DEV bool group_bad(const T* x, int n, int lane)
   return gsumi<G>(bad) != 0;
 }
 template <typename T, int G> MJB_DEV void reset_state(Ctx<T>& c) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; T* w = c.w;
+  MJB_ENV(c); T* w = c.w;
   for (int i = c.lane; i < m.nq; i += G) w[L.qpos + i] = m.qpos0[i];
   for (int i = c.lane; i < m.nv; i += G) { w[L.qvel + i] = 0; w[L.qacc + i] = 0; w[L.qacc_ws + i] = 0; }
   for (int i = c.lane; i < m.nu; i += G) w[L.ctrl + i] = 0;
@@ -1350,7 +1405,7 @@ template <typename T, int G> MJB_DEV void reset_state(Ctx<T>& c) {
 // flat observation (keys in sorted order, reference observations.py:171-174):
 // bodies_pos, ctrl, geoms_pos, qpos, qvel, sensordata, sites_pos, subtree_com, time
 template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c, const ObsSpecDev& s, double time, TS* out) {
-  const DevModel<T>& m = c.m; const Lay& L = c.L; const T* w = c.w; const int lane = c.lane;
+  ModelRef<T> m = *c.mp; LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
   int o = 0;
   const T* bsrc = (s.flags & 64) ? w + L.xipos : w + L.xpos;
   for (int i = lane; i < 3 * s.nbody; i += G) out[o + i] = (TS)bsrc[3 * s.body_ids[i / 3] + i % 3];
@@ -1372,9 +1427,10 @@ template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c
 // the per-environment driver: load -> nstep x (ctrl, forward, integrate) -> store
 // ---------------------------------------------------------------------------
 template <typename T, typename TS, int G>
-MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
+MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
                      const ObsSpecDev& obs, TS* obs_out, T* w, int* wi, int env, int lane) {
-  Ctx<T> c(m, L, w, wi, lane);
+  Ctx<T> c(mp, lp, w, wi, lane);
+  ModelRef<T> m = *mp; LayRef L = *lp;
   const int nq = m.nq, nv = m.nv, nu = m.nu;
   for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
   for (int i = lane; i < nv; i += G) {
@@ -1478,7 +1534,7 @@ MJB_DEV void env_run(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, c
       dbg.efc_D[(size_t)env * ne + i] = (TS)w[L.efc_D + i];
       dbg.efc_pos[(size_t)env * ne + i] = (TS)w[L.efc_pos + i];
       dbg.efc_force[(size_t)env * ne + i] = (TS)w[L.efc_force + i];
-      dbg.efc_type[(size_t)env * ne + i] = wi[L.i_efc_type + i];
+      dbg.efc_type[(size_t)env * ne + i] = wi[L.i_efc_type + i] & 0xff;
     }
   }
   if (dbg.con) for (int i = lane; i < c.ncon * CON_STRIDE; i += G) dbg.con[(size_t)env * m.ncon_max * CON_STRIDE + i] = (TS)w[L.con + i];

@@ -163,18 +163,21 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   // fp32 cannot resolve MuJoCo's 1e-8 scaled tolerance; floor it at what single precision supports
   m.tolerance = (T)h.tolerance;
   if (sizeof(T) == 4 && m.tolerance < (T)1e-6) m.tolerance = (T)1e-6;
-  auto F = [&](const char* k) -> const T* {
+  typedef typename DevModel<T>::FP FP;
+  typedef typename DevModel<T>::IP IP;
+  typedef typename DevModel<T>::UP UP;
+  auto F = [&](const char* k) -> FP {
     const auto& v = h.D(k);
     std::vector<T> tv(v.begin(), v.end());
-    return alloc.putf(tv);
+    return (FP)alloc.putf(tv);
   };
-  auto Iq = [&](const char* k) -> const int* { return alloc.puti(h.I(k)); };
+  auto Iq = [&](const char* k) -> IP { return (IP)alloc.puti(h.I(k)); };
   m.body_parentid = Iq("body_parentid"); m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
   m.body_dofadr = Iq("body_dofadr"); m.body_dofnum = Iq("body_dofnum");
-  m.level_adr = alloc.puti(h.level_adr); m.level_body = alloc.puti(h.level_body); m.child_adr = alloc.puti(h.child_adr); m.child_id = alloc.puti(h.child_id); m.tri_tab = alloc.puti(h.tri_tab);
+  m.level_adr = (IP)alloc.puti(h.level_adr); m.level_body = (IP)alloc.puti(h.level_body); m.child_adr = (IP)alloc.puti(h.child_adr); m.child_id = (IP)alloc.puti(h.child_id); m.tri_tab = (IP)alloc.puti(h.tri_tab);
   m.body_pos = F("body_pos"); m.body_quat = F("body_quat"); m.body_ipos = F("body_ipos"); m.body_iquat = F("body_iquat"); m.body_mass = F("body_mass");
   m.body_inertia = F("body_inertia"); m.body_subtreemass = F("body_subtreemass"); m.body_invweight0 = F("body_invweight0");
-  m.body_dofmask = alloc.putu(h.body_dofmask); m.dof_ancmask = alloc.putu(h.dof_ancmask);
+  m.body_dofmask = (UP)alloc.putu(h.body_dofmask); m.dof_ancmask = (UP)alloc.putu(h.dof_ancmask);
   m.jnt_type = Iq("jnt_type"); m.jnt_qposadr = Iq("jnt_qposadr"); m.jnt_dofadr = Iq("jnt_dofadr"); m.jnt_bodyid = Iq("jnt_bodyid"); m.jnt_limited = Iq("jnt_limited");
   m.jnt_pos = F("jnt_pos"); m.jnt_axis = F("jnt_axis"); m.jnt_range = F("jnt_range"); m.jnt_stiffness = F("jnt_stiffness"); m.jnt_margin = F("jnt_margin");
   m.jnt_solref = F("jnt_solref"); m.jnt_solimp = F("jnt_solimp"); m.qpos0 = F("qpos0"); m.qpos_spring = F("qpos_spring");

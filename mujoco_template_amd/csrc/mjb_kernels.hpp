@@ -10,14 +10,16 @@
 namespace mjb {
 
 template <typename T, typename TS, int G>
-__global__ __launch_bounds__(64, 2) void k_step(DevModel<T> m, Lay L, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
+__global__ __launch_bounds__(64, 2) void k_step(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
   extern __shared__ __align__(16) char smem[];
   const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
   const int env = blockIdx.x * (64 / G) + sub;
   if (env >= d.batch) return;
-  T* w = (T*)(smem + (size_t)sub * L.bytes);
-  int* wi = (int*)(w + L.nT);
-  env_run<T, TS, G>(m, L, d, dbg, a, obs, obs_out, w, wi, env, lane);
+  const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)mg;
+  const Lay MJB_CONST* lp = (const Lay MJB_CONST*)lg;
+  T* w = (T*)(smem + (size_t)sub * lp->bytes);
+  int* wi = (int*)(w + lp->nT);
+  env_run<T, TS, G>(mp, lp, d, dbg, a, obs, obs_out, w, wi, env, lane);
 }
 
 // Finite-difference columns of mjd_transitionFD (reference linearization.py:16-35): each group
@@ -25,15 +27,18 @@ __global__ __launch_bounds__(64, 2) void k_step(DevModel<T> m, Lay L, DevData<TS
 //   col 0 = nominal, col 1+2k = +eps on input k, col 2+2k = -eps;  k in [0, 2nv+nu): dq | dv | dctrl
 // y_out[(env*ncol + col) * (nq+nv)] = [qpos', qvel'];  valid[(env*ncol+col)] = 0 when a ctrl nudge left ctrlrange.
 template <typename T, typename TS, int G>
-__global__ __launch_bounds__(64) void k_fd(DevModel<T> m, Lay L, DevData<TS> d, int ncol, T eps, T* y_out, int* valid) {
+__global__ __launch_bounds__(64) void k_fd(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, int ncol, T eps, T* y_out, int* valid) {
   extern __shared__ __align__(16) char smem[];
   const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
   const long gid = (long)blockIdx.x * (64 / G) + sub;
   if (gid >= (long)d.batch * ncol) return;
   const int env = (int)(gid / ncol), col = (int)(gid % ncol);
+  const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)mg;
+  const Lay MJB_CONST* lp = (const Lay MJB_CONST*)lg;
+  ModelRef<T> m = *mp; LayRef L = *lp;
   T* w = (T*)(smem + (size_t)sub * L.bytes);
   int* wi = (int*)(w + L.nT);
-  Ctx<T> c(m, L, w, wi, lane);
+  Ctx<T> c(mp, lp, w, wi, lane);
   const int nq = m.nq, nv = m.nv, nu = m.nu;
   for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
   for (int i = lane; i < nv; i += G) {
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(64) void k_fd(DevModel<T> m, Lay L, DevData<TS> d, 
 
 // A = d[dq';dv']/d[dq;dv]  (2nv x 2nv), B = d[dq';dv']/dctrl (2nv x nu), row-major per environment.
 template <typename T>
-__global__ void k_fd_combine(DevModel<T> m, int batch, int ncol, int centered, T eps, const T* y, const int* valid, T* A, T* B) {
+__global__ void k_fd_combine(const DevModel<T>* mg, int batch, int ncol, int centered, T eps, const T* y, const int* valid, T* A, T* B) {
+  ModelRef<T> m = *(const DevModel<T> MJB_CONST*)mg;
   const int nq = m.nq, nv = m.nv, nu = m.nu, nin = 2 * nv + nu, nx = 2 * nv;
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (long)batch * nin) return;
@@ -116,14 +122,17 @@ __global__ void k_fd_combine(DevModel<T> m, int batch, int ncol, int centered, T
 // Jacobians (reference jacobians.py:26-83): kind 0 site, 1 body origin, 2 body com, 3 subtree com.
 // out_p / out_r: [batch, nreq, 3, nv]
 template <typename T, typename TS, int G>
-__global__ __launch_bounds__(64) void k_jac(DevModel<T> m, Lay L, DevData<TS> d, int nreq, const int* kinds, const int* ids, T* out_p, T* out_r) {
+__global__ __launch_bounds__(64) void k_jac(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, int nreq, const int* kinds, const int* ids, T* out_p, T* out_r) {
   extern __shared__ __align__(16) char smem[];
   const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
   const int env = blockIdx.x * (64 / G) + sub;
   if (env >= d.batch) return;
+  const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)mg;
+  const Lay MJB_CONST* lp = (const Lay MJB_CONST*)lg;
+  ModelRef<T> m = *mp; LayRef L = *lp;
   T* w = (T*)(smem + (size_t)sub * L.bytes);
   int* wi = (int*)(w + L.nT);
-  Ctx<T> c(m, L, w, wi, lane);
+  Ctx<T> c(mp, lp, w, wi, lane);
   const int nq = m.nq, nv = m.nv;
   for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
   gsync<G>();
@@ -196,12 +205,12 @@ __global__ void k_obs(DevData<TS> d, int nq, int nv, int nu, int nbody, int ngeo
 // launchers (defined in inst_*.hip)
 // ---------------------------------------------------------------------------
 template <typename T, typename TS>
-hipError_t launch_step(int G, const DevModel<T>& m, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
+hipError_t launch_step(int G, const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
                        const ObsSpecDev& obs, TS* obs_out, hipStream_t stream);
 template <typename T, typename TS>
-hipError_t launch_fd(int G, const DevModel<T>& m, const Lay& L, const DevData<TS>& d, int ncol, T eps, T* y, int* valid, hipStream_t stream);
+hipError_t launch_fd(int G, const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, int ncol, T eps, T* y, int* valid, hipStream_t stream);
 template <typename T, typename TS>
-hipError_t launch_jac(int G, const DevModel<T>& m, const Lay& L, const DevData<TS>& d, int nreq, const int* kinds, const int* ids, T* out_p, T* out_r, hipStream_t stream);
+hipError_t launch_jac(int G, const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, int nreq, const int* kinds, const int* ids, T* out_p, T* out_r, hipStream_t stream);
 
 #define MJB_DISPATCH_G(G, CALL)                    \
   switch (G) {                                     \
@@ -212,7 +221,7 @@ hipError_t launch_jac(int G, const DevModel<T>& m, const Lay& L, const DevData<T
   }
 
 template <typename T, typename TS, int G>
-hipError_t launch_step_g(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
+hipError_t launch_step_g(const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
                          const ObsSpecDev& obs, TS* obs_out, hipStream_t stream) {
   const int epb = 64 / G;
   size_t shmem = (size_t)epb * L.bytes;
@@ -220,11 +229,11 @@ hipError_t launch_step_g(const DevModel<T>& m, const Lay& L, const DevData<TS>& 
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return e;
   int grid = (d.batch + epb - 1) / epb;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, L, d, dbg, a, obs, obs_out);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, Ldev, d, dbg, a, obs, obs_out);
   return hipGetLastError();
 }
 template <typename T, typename TS, int G>
-hipError_t launch_fd_g(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, int ncol, T eps, T* y, int* valid, hipStream_t stream) {
+hipError_t launch_fd_g(const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, int ncol, T eps, T* y, int* valid, hipStream_t stream) {
   const int epb = 64 / G;
   size_t shmem = (size_t)epb * L.bytes;
   auto kern = k_fd<T, TS, G>;
@@ -232,18 +241,18 @@ hipError_t launch_fd_g(const DevModel<T>& m, const Lay& L, const DevData<TS>& d,
   if (e != hipSuccess) return e;
   long ngroups = (long)d.batch * ncol;
   int grid = (int)((ngroups + epb - 1) / epb);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, L, d, ncol, eps, y, valid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, Ldev, d, ncol, eps, y, valid);
   return hipGetLastError();
 }
 template <typename T, typename TS, int G>
-hipError_t launch_jac_g(const DevModel<T>& m, const Lay& L, const DevData<TS>& d, int nreq, const int* kinds, const int* ids, T* out_p, T* out_r, hipStream_t stream) {
+hipError_t launch_jac_g(const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, int nreq, const int* kinds, const int* ids, T* out_p, T* out_r, hipStream_t stream) {
   const int epb = 64 / G;
   size_t shmem = (size_t)epb * L.bytes;
   auto kern = k_jac<T, TS, G>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return e;
   int grid = (d.batch + epb - 1) / epb;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, L, d, nreq, kinds, ids, out_p, out_r);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, Ldev, d, nreq, kinds, ids, out_p, out_r);
   return hipGetLastError();
 }
 

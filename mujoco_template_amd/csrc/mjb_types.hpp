@@ -1,12 +1,20 @@
 // mjb_types.hpp — structures shared by the host API and the device kernels.
 //
 // DevModel<T>: the compiled model as device pointers (T = float for the product
-// path, double for the finite-difference / validation path).  Passed BY VALUE as
-// a kernel argument, so the pointers arrive in SGPRs through the kernarg segment.
+// path, double for the finite-difference / validation path).  A device copy of the
+// struct is read through the constant address space (scalar loads, phase-local).
 // Lay: per-environment LDS layout (offsets in elements of T / int), computed on
 // the host from the model sizes and the contact/constraint caps.
 #pragma once
 #include <cstdint>
+
+// Address spaces: model constants are read through the CONSTANT address space (invariant for the
+// whole launch -> uniform reads become scalar loads); the host emulation build has no address spaces.
+#if defined(MJB_HOST_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#define MJB_CONST
+#else
+#define MJB_CONST __attribute__((address_space(4)))
+#endif
 
 namespace mjb {
 
@@ -23,38 +31,41 @@ enum { CNT_NCON = 0, CNT_NEFC, CNT_NITER, CNT_CON_DROPPED, CNT_EFC_DROPPED, CNT_
 
 template <typename T>
 struct DevModel {
+  typedef const T MJB_CONST* FP;                     // float-type table
+  typedef const int MJB_CONST* IP;                   // int table
+  typedef const unsigned long long MJB_CONST* UP;    // 64-bit dof mask table
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nsensor, nsensordata, nkey, npair;
   int nlevel, integrator, disableactuator, iterations, has_damping, has_fluid, nvp, nvshift;
   int ncon_max, nefc_max;
   T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
   // kinematic tree
-  const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
-  const int *level_adr, *level_body, *child_adr, *child_id, *tri_tab;
-  const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_subtreemass, *body_invweight0;
-  const unsigned long long *body_dofmask, *dof_ancmask;
+  IP body_parentid, body_rootid, body_jntadr, body_jntnum, body_dofadr, body_dofnum;
+  IP level_adr, level_body, child_adr, child_id, tri_tab;
+  FP body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_subtreemass, body_invweight0;
+  UP body_dofmask, dof_ancmask;
   // joints / dofs
-  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
-  const T *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_margin, *jnt_solref, *jnt_solimp, *qpos0, *qpos_spring;
-  const int *dof_bodyid, *dof_jntid, *dof_parentid;
-  const T *dof_armature, *dof_damping, *dof_invweight0;
+  IP jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited;
+  FP jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_margin, jnt_solref, jnt_solimp, qpos0, qpos_spring;
+  IP dof_bodyid, dof_jntid, dof_parentid;
+  FP dof_armature, dof_damping, dof_invweight0;
   // geoms / sites
-  const int *geom_type, *geom_bodyid;
-  const T *geom_pos, *geom_quat, *geom_size;
-  const int* site_bodyid;
-  const T *site_pos, *site_quat;
+  IP geom_type, geom_bodyid;
+  FP geom_pos, geom_quat, geom_size;
+  IP site_bodyid;
+  FP site_pos, site_quat;
   // tendons
-  const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
-  const T *tendon_range, *tendon_margin, *tendon_solref, *tendon_solimp, *tendon_invweight0, *wrap_prm;
+  IP tendon_adr, tendon_num, tendon_limited, wrap_objid;
+  FP tendon_range, tendon_margin, tendon_solref, tendon_solimp, tendon_invweight0, wrap_prm;
   // actuators
-  const int *actuator_trntype, *actuator_trnid, *actuator_biastype, *actuator_ctrllimited, *actuator_forcelimited, *actuator_group;
-  const T *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  IP actuator_trntype, actuator_trnid, actuator_biastype, actuator_ctrllimited, actuator_forcelimited, actuator_group;
+  FP actuator_gear, actuator_gainprm, actuator_biasprm, actuator_ctrlrange, actuator_forcerange;
   // sensors
-  const int *sensor_type, *sensor_objid, *sensor_adr;
+  IP sensor_type, sensor_objid, sensor_adr;
   // collision pairs
-  const int *pair_geom1, *pair_geom2, *pair_condim;
-  const T *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  IP pair_geom1, pair_geom2, pair_condim;
+  FP pair_friction, pair_solref, pair_solimp, pair_margin, pair_gap;
   // keyframes
-  const T *key_qpos, *key_qvel, *key_ctrl, *key_time;
+  FP key_qpos, key_qvel, key_ctrl, key_time;
 };
 
 // Per-environment LDS layout.  Offsets of T arrays are in units of T from the
