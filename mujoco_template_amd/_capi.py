@@ -19,7 +19,7 @@ from .exceptions import ConfigError, NameLookupError, TemplateError
 from .mjcf import CompiledModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmjbatch.so")
+_LIB_PATH = os.path.join(_HERE, "libmjbatch_prof.so" if os.environ.get("MJB_PROFILE") == "1" else "libmjbatch.so")
 _LIB: ctypes.CDLL | None = None
 
 MJB_F32, MJB_F64 = 0, 1
@@ -76,6 +76,8 @@ def load_library() -> ctypes.CDLL:
     L.mjb_obs_gather.argtypes = [vp, vp, vp]
     L.mjb_transition_fd.argtypes = [vp, cd, ci, vp, vp]
     L.mjb_jac.argtypes = [vp, ci, vp, vp, vp, vp]
+    L.mjb_profile_get.argtypes = [vp, vp]
+    L.mjb_profile_get.restype = ci
     L.mjb_debug_forward.argtypes = [vp]
     L.mjb_debug_get.argtypes = [vp, ctypes.c_char_p, vp, cl]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
@@ -261,6 +263,11 @@ class BatchSim:
         jr = np.zeros((self.batch, k.size, 3, m.nv))
         _check(load_library().mjb_jac(self.ptr, k.size, kp, ip, jp.ctypes.data, jr.ctypes.data))
         return jp, jr
+
+    def profile_get(self) -> np.ndarray:
+        out = np.zeros(16, dtype=np.uint64)
+        _check(load_library().mjb_profile_get(self.ptr, out.ctypes.data))
+        return out
 
     def debug_forward(self) -> None:
         _check(load_library().mjb_debug_forward(self.ptr))

@@ -105,6 +105,7 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   rc |= dev_alloc(d, &s.site_xpos, B * h.nsite * 3); rc |= dev_alloc(d, &s.geom_xpos, B * h.ngeom * 3);
   rc |= dev_alloc(d, &s.subtree_com, B * h.nbody * 3); rc |= dev_alloc(d, &s.sensordata, B * h.nsensordata);
   rc |= dev_alloc(d, &s.counters, B * CNT_N);
+  rc |= dev_alloc(d, &s.prof, (size_t)PH_N);
   if (rc) return -1;
   auto& A = d->arrays;
   A["qpos"] = {s.qpos, h.nq, 0}; A["qvel"] = {s.qvel, h.nv, 0}; A["ctrl"] = {s.ctrl, h.nu, 0}; A["qacc"] = {s.qacc, h.nv, 0};
@@ -493,6 +494,16 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
   }
   (void)hipFree(op); (void)hipFree(orr); (void)hipFree(dk); (void)hipFree(di);
   return rc;
+}
+
+int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [16] per-phase cycle sums; zero unless built with -DMJB_PROFILE */) {
+  if (!d || !host_out) return fail(MJB_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  void* p = d->dtype == MJB_F32 ? (void*)d->df.prof : (void*)d->dd.prof;
+  HIPCHK(hipMemcpy(host_out, p, sizeof(unsigned long long) * PH_N, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(p, 0, sizeof(unsigned long long) * PH_N));
+  return MJB_OK;
 }
 
 int mjb_debug_forward(mjbData* d) {

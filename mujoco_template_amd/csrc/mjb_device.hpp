@@ -290,6 +290,87 @@ template <typename T, int G> MJB_DEV void chol_solve(const T* L, const T* dinv, 
 }
 
 // ---------------------------------------------------------------------------
+// Register-tiled Cholesky for one wavefront per environment (G == 64).  The 64 lanes form an 8x8 grid; lane
+// (lr, lc) keeps the entries A[8a+lr][8b+lc], a,b < NB, in registers for the whole factorisation.  Per column
+// only the pivot and the scaled column cross lanes (through LDS): 2 syncs and no table lookups per column.
+//   mode 0: A = M      mode 1: A = M + J^T diag(dw) J (dw = D on active rows)      mode 2: A = M + h diag(damping)
+// Result: L (lower) in W, 1/diag(L) in dinv — the layout chol_solve expects.
+// ---------------------------------------------------------------------------
+template <typename T, int NB, typename MRef>
+MJB_DEV void tile_factor(MRef m, const T* M, T* W, T* dinv, T* col, const T* J, const T* dw, int nefc, int mode, int n, int lane) {
+  const int lr = lane >> 3, lc = lane & 7;
+  T e[NB][NB];
+#pragma unroll
+  for (int a = 0; a < NB; a++)
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      int r = 8 * a + lr, cc = 8 * b + lc;
+      e[a][b] = (r < n && cc <= r) ? M[r * n + cc] : (T)0;
+    }
+  if (mode == 1) {
+    for (int row = 0; row < nefc; row++) {
+      T d = dw[row];
+      if (d == 0) continue;
+      T jr[NB], jc[NB];
+#pragma unroll
+      for (int a = 0; a < NB; a++) { int r = 8 * a + lr; jr[a] = r < n ? d * J[row * n + r] : (T)0; }
+#pragma unroll
+      for (int b = 0; b < NB; b++) { int cc = 8 * b + lc; jc[b] = cc < n ? J[row * n + cc] : (T)0; }
+#pragma unroll
+      for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) e[a][b] += jr[a] * jc[b];
+    }
+  } else if (mode == 2) {
+    if (lr == lc) {
+#pragma unroll
+      for (int a = 0; a < NB; a++) { int r = 8 * a + lr; if (r < n) e[a][a] += m.timestep * m.dof_damping[r]; }
+    }
+  }
+  for (int j = 0; j < n; j++) {
+    const int bj = j >> 3, lj = j & 7;
+    if (lr == lj && lc == lj) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) if (b == bj) col[n] = e[b][b];
+    }
+    gsync<64>();
+    const T ljj = t_sqrt(t_max(col[n], Num<T>::minval()));
+    const T inv = 1 / ljj;
+    if (lc == lj) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        if (b != bj) continue;
+#pragma unroll
+        for (int a = 0; a < NB; a++) {
+          int r = 8 * a + lr;
+          if (r > j && r < n) { T v = e[a][b] * inv; e[a][b] = v; col[r] = v; }
+          else if (r == j) e[a][b] = ljj;
+        }
+      }
+    }
+    if (lane == 0) dinv[j] = inv;
+    gsync<64>();
+    T rv[NB], cv[NB];
+#pragma unroll
+    for (int a = 0; a < NB; a++) { int r = 8 * a + lr; rv[a] = (r > j && r < n) ? col[r] : (T)0; }
+#pragma unroll
+    for (int b = 0; b < NB; b++) { int cc = 8 * b + lc; cv[b] = (cc > j && cc < n) ? col[cc] : (T)0; }
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+      for (int b = 0; b < NB; b++) e[a][b] -= rv[a] * cv[b];
+  }
+#pragma unroll
+  for (int a = 0; a < NB; a++)
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      int r = 8 * a + lr, cc = 8 * b + lc;
+      if (r < n && cc <= r) W[r * n + cc] = e[a][b];
+    }
+  gsync<64>();
+}
+
+// ---------------------------------------------------------------------------
 // environment context: LDS slice + model, passed to every phase
 // ---------------------------------------------------------------------------
 // Re-materialise the model / layout pointers at the start of every phase: the (invariant) loads through
@@ -303,6 +384,11 @@ template <typename T, int G> MJB_DEV void chol_solve(const T* L, const T* dinv, 
   asm volatile("" : "+s"(mp_), "+s"(lp_));             \
   ModelRef<T> m = *mp_; LayRef L = *lp_
 #endif
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+#define MJB_STAMP(c, k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).pacc[k] += t_ - (c).pt; (c).pt = t_; } while (0)
+#else
+#define MJB_STAMP(c, k) ((void)0)
+#endif
 template <typename T> using ModelRef = const DevModel<T> MJB_CONST&;
 typedef const Lay MJB_CONST& LayRef;
 
@@ -313,8 +399,104 @@ template <typename T> struct Ctx {
   int* wi;   // int region
   int lane;
   int ncon, nefc, niter, con_dropped, efc_dropped;
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+  unsigned long long pacc[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pt = 0;
+#endif
   MJB_DEVM Ctx(const DevModel<T> MJB_CONST* m_, const Lay MJB_CONST* L_, T* w_, int* wi_, int lane_) : mp(m_), lp(L_), w(w_), wi(wi_), lane(lane_), ncon(0), nefc(0), niter(0), con_dropped(0), efc_dropped(0) {}
 };
+
+// ---------------------------------------------------------------------------
+// Row-per-lane Cholesky in registers (G == 64, n <= 32): lane i keeps row i (padded to 32 with identity) in 32
+// VGPRs; a column step is one v_readlane + one FMA per trailing column — no LDS, no sync, no branches.
+// Entries above the diagonal hold garbage that is never read.  Modes as tile_factor.
+// ---------------------------------------------------------------------------
+#ifndef MJB_HOST_EMU
+template <typename T, typename MRef>
+MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T* dw, int nefc, int mode, int n, int lane, T* x) {
+  T a[32];
+  const bool own = lane < n;
+#pragma unroll
+  for (int k = 0; k < 32; k++) a[k] = (own && k < n) ? M[lane * n + k] : ((k == lane) ? (T)1 : (T)0);
+  if (mode == 1) {
+    for (int row = 0; row < nefc; row++) {
+      T d = dw[row];
+      if (d == 0) continue;
+      T jrow = own ? J[row * n + lane] : (T)0;
+      T s = d * jrow;
+#pragma unroll
+      for (int k = 0; k < 32; k++) a[k] += s * rdlane_f(jrow, k);
+    }
+  } else if (mode == 2) {
+    T dd = own ? m.timestep * m.dof_damping[lane] : (T)0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) if (k == lane) a[k] += dd;
+  }
+  T myinv = 1;
+  T r = (x && own) ? x[lane] : (T)0;          // fused forward substitution L y = b (b = x on entry)
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    T ajj = rdlane_f(a[j], j);
+    T ljj = t_sqrt(t_max(ajj, Num<T>::minval()));
+    T inv = 1 / ljj;
+    a[j] = lane == j ? ljj : a[j] * inv;
+    if (lane == j) myinv = inv;
+    T yj = rdlane_f(r, j) * inv;
+    r = lane > j ? r - a[j] * yj : (lane == j ? yj : r);
+#pragma unroll
+    for (int k = j + 1; k < 32; k++) a[k] -= a[j] * rdlane_f(a[j], k);
+  }
+  if (own) {
+#pragma unroll
+    for (int k = 0; k < 32; k++) if (k < n) W[lane * n + k] = a[k];
+    dinv[lane] = myinv;
+  }
+  gsync<64>();
+  if (x) {                                      // backward substitution L^T x = y: row j of L comes back from LDS
+    T lrow[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) lrow[j] = (j < n && lane < j) ? W[j * n + lane] : (T)0;
+#pragma unroll
+    for (int j = 31; j >= 0; j--) {
+      T xj = rdlane_f(r, j) * rdlane_f(myinv, j);
+      r = lane == j ? xj : r - lrow[j] * xj;
+    }
+    if (own) x[lane] = r;
+    gsync<64>();
+  }
+}
+#endif
+
+// W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
+// If x != nullptr the system (factor) x = x is solved in the same pass (fused on the register path).
+template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *dw = w + L.efc_jv;
+  if (G == 64) {
+#ifndef MJB_HOST_EMU
+    if (nv <= 32) { reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x); return; }
+#endif
+    tile_factor<T, 8, ModelRef<T>>(m, M, W, w + L.tmp, w + L.cholcol, J, dw, nefc, mode, nv, lane);
+    if (x) chol_solve<T, G>(W, w + L.tmp, x, nv, lane);
+    return;
+  }
+  int np = nv * (nv + 1) / 2;
+  for (int idx = lane; idx < np; idx += G) {
+    int i, k;
+    tri_rc(m.tri_tab, idx, i, k);
+    T h = M[i * nv + k];
+    if (mode == 1) {
+      for (int r = 0; r < nefc; r++) {
+        T d = dw[r];
+        if (d != 0) h += d * J[r * nv + i] * J[r * nv + k];
+      }
+    } else if (mode == 2 && i == k) h += m.timestep * m.dof_damping[i];
+    W[i * nv + k] = h;
+  }
+  gsync<G>();
+  chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
+  if (x) chol_solve<T, G>(W, w + L.tmp, x, nv, lane);
+}
 
 // ---------------------------------------------------------------------------
 // A1 kinematics: tree levels in order, bodies of a level across lanes
@@ -572,10 +754,8 @@ template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
       if (i == j) val += m.dof_armature[i];
     }
     M[i * nv + j] = val; M[j * nv + i] = val;
-    W[i * nv + j] = val;
   }
-  gsync<G>();
-  chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
+  gsync<G>();     // M stays unfactored here: it is factored together with the M^-1 solve in actuation_acceleration
 }
 
 // ---------------------------------------------------------------------------
@@ -1122,7 +1302,7 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
     qs[i] = fs; qas[i] = fs;
   }
   gsync<G>();
-  chol_solve<T, G>(w + L.W, w + L.tmp, qas, nv, lane);
+  factor_W<T, G>(c, 0, qas);
 }
 
 // ---------------------------------------------------------------------------
@@ -1176,22 +1356,8 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first) {
   T gn = gsum<T, G>(gpart);
   const bool rebuild = gsumi<G>(chg) != 0;
   gsync<G>();
-  if (rebuild) {
-    int np = nv * (nv + 1) / 2;
-    for (int idx = lane; idx < np; idx += G) {
-      int i, k;
-      tri_rc(m.tri_tab, idx, i, k);
-      T h = M[i * nv + k];
-      for (int r = 0; r < nefc; r++) {
-        T d = dw[r];
-        if (d != 0) h += d * J[r * nv + i] * J[r * nv + k];
-      }
-      W[i * nv + k] = h;
-    }
-    gsync<G>();
-    chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
-  }
-  chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
+  if (rebuild) factor_W<T, G>(c, 1, search);
+  else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
   for (int i = lane; i < nv; i += G) search[i] = -search[i];
   gsync<G>();
   return gn;
@@ -1222,7 +1388,9 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   gsync<G>();
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
   for (int iter = 0; iter < m.iterations; iter++) {
+    MJB_STAMP(c, PH_SOLVE);
     T gn = newton_direction<T, G>(c, iter == 0);
+    MJB_STAMP(c, PH_SOL_DIR);
     if (scale * t_sqrt(gn) < m.tolerance) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
@@ -1257,6 +1425,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
       if (an == alpha) break;
       alpha = an;
     }
+    MJB_STAMP(c, PH_SOL_LS);
     if (alpha == 0) break;
     T part = 0;
     for (int i = lane; i < nv; i += G) {
@@ -1287,14 +1456,15 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
 // mj_forward for one environment (state in LDS)
 // ---------------------------------------------------------------------------
 template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
-  kinematics<T, G>(c);
-  com_pos<T, G>(c);
-  crb_factor<T, G>(c);
-  collision<T, G>(c);
-  make_constraint<T, G>(c);
-  vel_bias_passive<T, G>(c);
-  actuation_acceleration<T, G>(c);
-  solve_constraints<T, G>(c);
+  MJB_STAMP(c, PH_OTHER);
+  kinematics<T, G>(c); MJB_STAMP(c, PH_KIN);
+  com_pos<T, G>(c); MJB_STAMP(c, PH_COM);
+  crb_factor<T, G>(c); MJB_STAMP(c, PH_CRB);
+  collision<T, G>(c); MJB_STAMP(c, PH_COLL);
+  make_constraint<T, G>(c); MJB_STAMP(c, PH_CONS);
+  vel_bias_passive<T, G>(c); MJB_STAMP(c, PH_VEL);
+  actuation_acceleration<T, G>(c); MJB_STAMP(c, PH_ACT);
+  solve_constraints<T, G>(c); MJB_STAMP(c, PH_SOLVE);
 }
 
 // A16 position integration for the joints of one environment (lanes over joints)
@@ -1318,15 +1488,8 @@ template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
   if (m.has_damping) {
     T *qs = w + L.qfrc_smooth, *qc = w + L.qfrc_constraint;
     for (int i = lane; i < nv; i += G) tmpv[i] = qs[i] + qc[i];
-    int np = nv * (nv + 1) / 2;
-    for (int idx = lane; idx < np; idx += G) {
-      int i, k;
-      tri_rc(m.tri_tab, idx, i, k);
-      W[i * nv + k] = M[i * nv + k] + (i == k ? h * m.dof_damping[i] : (T)0);
-    }
     gsync<G>();
-    chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
-    chol_solve<T, G>(W, w + L.tmp, tmpv, nv, lane);
+    factor_W<T, G>(c, 2, tmpv);
   } else {
     for (int i = lane; i < nv; i += G) tmpv[i] = qacc[i];
     gsync<G>();
@@ -1442,6 +1605,9 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
   double time = d.time[env];
   int badqpos = 0, badqvel = 0, badqacc = 0;
   gsync<G>();
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+  c.pt = __builtin_amdgcn_s_memtime();
+#endif
   const int nstep = a.mode == 1 ? 1 : a.nstep;
   const int nstage = (a.mode == 0 && m.integrator == INT_RK4) ? 4 : 1;
   for (int s = 0; s < nstep; s++) {
@@ -1465,12 +1631,16 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     }
     if (a.mode == 1) break;
     if (nstage == 1) euler<T, G>(c);
+    MJB_STAMP(c, PH_INTEG);
     time += a.dt;
     if (a.obs_every > 0 && ((s + 1) % a.obs_every) == 0) {
       size_t slot = (size_t)((s + 1) / a.obs_every - 1);
       write_obs<T, TS, G>(c, obs, time, obs_out + (slot * (size_t)d.batch + (size_t)env) * (size_t)obs.dim);
     }
   }
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+  if (lane == 0 && d.prof) for (int k = 0; k < PH_N; k++) atomicAdd(d.prof + k, c.pacc[k]);
+#endif
   // store state
   for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
   for (int i = lane; i < nv; i += G) {

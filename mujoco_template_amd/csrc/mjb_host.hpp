@@ -214,7 +214,7 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   L.con = A(ncon_max * CON_STRIDE);
   L.efc_J = A(nefc_max * nv); L.efc_pos = A(nefc_max); L.efc_D = A(nefc_max); L.efc_aref = A(nefc_max); L.efc_jar = A(nefc_max);
   L.efc_jv = A(nefc_max); L.efc_force = A(nefc_max); L.efc_KBI = A(nefc_max);
-  L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.tmp = A(nv);
+  L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.tmp = A(nv); L.cholcol = A(nv + 1);
   L.rk = A(h.integrator == INT_RK4 ? nq + nv + 8 * nv + nv : 0);
   L.nT = o;
   int oi = 0;

@@ -79,7 +79,7 @@ struct Lay {
   int M, W, ten_length, ten_J, act_force;
   int con;            // contacts: ncon_max * CON_STRIDE
   int efc_J, efc_pos, efc_D, efc_aref, efc_jar, efc_jv, efc_force, efc_KBI;
-  int Ma, grad, search, Mv, tmp;
+  int Ma, grad, search, Mv, tmp, cholcol;   // tmp = 1/diag(L); cholcol = scaled pivot column (nv+1)
   int rk;             // RK4 scratch: X0 (nq+nv) + F (4*2*nv) + dX (2*nv)
   int nT;             // total T elements
   int i_efc_type, i_efc_id, i_con_pair, i_scal;  // int arrays
@@ -97,7 +97,9 @@ struct DevData {
   double* time;
   TS *xpos, *xquat, *xipos, *site_xpos, *geom_xpos, *subtree_com, *sensordata;
   int* counters;
+  unsigned long long* prof;   // per-phase cycle sums (diagnostic -DMJB_PROFILE build only; null otherwise)
 };
+enum { PH_KIN = 0, PH_COM, PH_CRB, PH_COLL, PH_CONS, PH_VEL, PH_ACT, PH_SOLVE, PH_INTEG, PH_OTHER, PH_SOL_DIR, PH_SOL_LS, PH_N = 16 };
 
 // optional per-phase dumps for parity tests (device pointers, may be null)
 template <typename TS>

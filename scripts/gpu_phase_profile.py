@@ -1,0 +1,19 @@
+"""Per-phase cycle shares of k_step (diagnostic build: make -C mujoco_template_amd/csrc prof; MJB_PROFILE=1)."""
+import os, sys
+os.environ["MJB_PROFILE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mujoco_template_amd.mjcf import compile_xml_path
+from mujoco_template_amd._capi import BatchSim, DeviceModel, CTRL_RANDOM
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+sim = BatchSim(DeviceModel(compile_xml_path(os.path.join(ROOT, "models/humanoid.xml"))), B, dtype="float32")
+sim.rollout(50, CTRL_RANDOM, seed=1); sim.sync(); sim.profile_get()
+n = 100
+sim.rollout(n, CTRL_RANDOM, seed=1, step0=50); sim.sync()
+p = sim.profile_get().astype(float) / (B * n)
+names = ["kinematics", "com_pos", "crb+factorM", "collision", "constraints", "vel/bias/passive", "actuation+Msolve", "solver(rest)", "integrate(euler)", "other", "solver:direction(H,chol,solve)", "solver:linesearch"]
+tot = p.sum()
+print(f"B={B}: cycles per env-step {tot:.0f}")
+for k, nm in enumerate(names):
+    print(f"  {nm:34s} {p[k]:9.0f}  {100*p[k]/tot:5.1f}%")

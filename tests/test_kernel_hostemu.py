@@ -58,10 +58,14 @@ def test_humanoid_contacts_wave64_and_fp32(compiled):
     assert np.abs(e.efc_aref[:32] - od.efc_aref).max() < 1e-9
     assert np.abs(e.efc_D[:32] - od.efc_D).max() < 1e-9 * od.efc_D.max()
     assert np.abs(e.qacc - od.qacc).max() < 1e-9
+    # one full step with the wavefront-wide (G = 64) path: register-tiled Cholesky of M, M + J^T D J and M + h D
+    e.step(); od.step()
+    assert np.abs(e.qpos - od.qpos).max() < 1e-12 and np.abs(e.qvel - od.qvel).max() < 1e-9
+    od.reset(); od.forward()
     # fp32 instantiation of the same source: single-step error at fp32 level
     e32 = EmuEnv(cm, G=16, use_double=False)
     e32.step()
-    od.step()
+    od.reset(); od.step()
     assert np.abs(e32.qpos - od.qpos).max() < 2e-6
 
 
