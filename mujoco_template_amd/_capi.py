@@ -277,7 +277,7 @@ class BatchSim:
         nv = m.nv
         per = {"qM": nv * nv, "qfrc_bias": nv, "qfrc_passive": nv, "qfrc_actuator": nv, "qacc_smooth": nv, "qfrc_constraint": nv,
                "efc_J": self.nefcmax * nv, "efc_aref": self.nefcmax, "efc_D": self.nefcmax, "efc_pos": self.nefcmax,
-               "efc_force": self.nefcmax, "con": self.nconmax * 14, "cdof": 6 * nv, "cinert": 10 * m.nbody, "cvel": 6 * m.nbody,
+               "efc_force": self.nefcmax, "con": self.nconmax * 11, "cdof": 6 * nv, "cinert": 10 * m.nbody, "cvel": 6 * m.nbody,
                "efc_type": self.nefcmax}[name]
         out = np.zeros((self.batch, per), dtype=np.int32 if name == "efc_type" else np.float64)
         _check(load_library().mjb_debug_get(self.ptr, name.encode(), out.ctypes.data, out.size))

@@ -229,9 +229,22 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
   if (lanes != 8 && lanes != 16 && lanes != 64) return fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64");
   mjbData* d = new mjbData();
   d->model = m; d->batch = batch; d->dtype = dtype; d->G = lanes; d->device = device; d->env0 = env0; d->stream = nullptr;
-  // default caps: 32 contacts / 96 rows per environment (humanoid worst case seen: 13 contacts, 54 rows); drops are counted
-  d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 32 ? h.ncon_alloc : 32);
-  d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 96 ? h.nefc_alloc : 96);
+  // Caps on contacts / constraint rows held in LDS per environment.  Explicit values are taken as given; the default
+  // is the largest (rows <= 96, contacts = 3/8 rows) that still lets 8 fp32 (4 fp64) environments share one CU's
+  // 160 KiB — the occupancy step that matters most for throughput (profiles/).  Overflow drops rows and is COUNTED.
+  if (nconmax > 0 || nefcmax > 0) {
+    d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 32 ? h.ncon_alloc : 32);
+    d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 96 ? h.nefc_alloc : 96);
+  } else {
+    const size_t budget = (size_t)160 * 1024 / (dtype == MJB_F32 ? 8 : 4);
+    int ne = h.nefc_alloc < 96 ? h.nefc_alloc : 96, nc = 0;
+    for (;; ne -= 8) {
+      nc = ne * 3 / 8; if (nc < 8) nc = 8; if (nc > h.ncon_alloc) nc = h.ncon_alloc;
+      Lay t = make_layout(h, nc > 0 ? nc : 1, ne > 0 ? ne : 1, dtype == MJB_F32 ? sizeof(float) : sizeof(double));
+      if ((size_t)(64 / lanes) * (size_t)t.bytes <= budget || ne <= 32) break;
+    }
+    d->nefc_max = ne; d->ncon_max = nc;
+  }
   if (d->ncon_max < 1) d->ncon_max = 1;
   if (d->nefc_max < 1) d->nefc_max = 1;
   fill_dev_model<float>(h, d->alloc, d->ncon_max, d->nefc_max, d->mf);

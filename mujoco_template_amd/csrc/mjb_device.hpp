@@ -98,6 +98,24 @@ template <> struct Num<float> {
 template <> struct Num<double> {
   MJB_DEVM static double minval() { return 1e-15; }
 };
+// x[k] for a group-uniform k, n <= 64: with one wavefront per environment the vector lives in one VGPR and is
+// broadcast with v_readlane (scalar lane select) instead of an LDS read; otherwise it is read from LDS.
+template <typename T, int G> struct VecBcast {
+  const T* x;
+  T r0;
+  MJB_DEVM VecBcast(const T* x_, int n, int lane) : x(x_), r0(0) {
+#ifndef MJB_HOST_EMU
+    if (G == 64 && lane < n) r0 = x_[lane];
+#endif
+  }
+  MJB_DEVM T get(int k) const {
+#ifndef MJB_HOST_EMU
+    if (G == 64) return rdlane_f(r0, k);
+#endif
+    return x[k];
+  }
+};
+
 #define MJB_MINIMP ((T)0.0001)
 #define MJB_MAXIMP ((T)0.9999)
 #define MJB_PI ((T)3.14159265358979323846)
@@ -107,6 +125,12 @@ template <typename T> MJB_DEV T t_min(T a, T b) { return a < b ? a : b; }
 template <typename T> MJB_DEV T t_abs(T a) { return a < 0 ? -a : a; }
 MJB_DEV float t_sqrt(float a) { return sqrtf(a); }
 MJB_DEV double t_sqrt(double a) { return sqrt(a); }
+#ifndef MJB_HOST_EMU
+MJB_DEV float t_rsqrt(float a) { float y = __builtin_amdgcn_rsqf(a); return y * (1.5f - 0.5f * a * y * y); }
+#else
+MJB_DEV float t_rsqrt(float a) { return 1.0f / sqrtf(a); }
+#endif
+MJB_DEV double t_rsqrt(double a) { return 1.0 / sqrt(a); }
 MJB_DEV float t_sin(float a) { return sinf(a); }
 MJB_DEV double t_sin(double a) { return sin(a); }
 MJB_DEV float t_cos(float a) { return cosf(a); }
@@ -154,9 +178,19 @@ template <typename T> MJB_DEV void quat2mat(T* m, const T* q) {
   m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
 }
+// sin/cos of a half joint angle.  fp32: minimax polynomials on |x| <= pi/2 (|error| < 1.5e-7, i.e. fp32 rounding level);
+// joint angles beyond +-pi fall back to the library functions.  fp64: library functions.
+MJB_DEV void half_sincos(float x, float& s, float& c) {
+  if (x > 1.5708f || x < -1.5708f) { s = sinf(x); c = cosf(x); return; }
+  float x2 = x * x;
+  s = x * (1.0f + x2 * (-1.6666667e-1f + x2 * (8.3333310e-3f + x2 * (-1.9840874e-4f + x2 * (2.7525562e-6f + x2 * -2.3889859e-8f)))));
+  c = 1.0f + x2 * (-0.5f + x2 * (4.1666668e-2f + x2 * (-1.3888889e-3f + x2 * (2.4801587e-5f + x2 * (-2.7557314e-7f + x2 * 2.0875723e-9f)))));
+}
+MJB_DEV void half_sincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
 template <typename T> MJB_DEV void axisangle2quat(T* q, const T* axis, T angle) {
-  T s = t_sin(angle * (T)0.5);
-  q[0] = t_cos(angle * (T)0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+  T s, cs;
+  half_sincos(angle * (T)0.5, s, cs);
+  q[0] = cs; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 template <typename T> MJB_DEV void quat_integrate(T* q, const T* w, T h) {
   T ax[3] = {w[0], w[1], w[2]};
@@ -224,8 +258,10 @@ template <typename T> MJB_DEV void cross_force(T* res, const T* vel, const T* f)
   res[5] = -vel[1] * f[3] + vel[0] * f[4];
 }
 
+MJB_DEV int tri_at(int r, int c) { return r * (r + 1) / 2 + c; }   // packed lower-triangular index (c <= r)
+
 // triangle enumeration idx -> (r, c), 0 <= c <= r, idx = r(r+1)/2 + c: host-built table (r << 16 | c)
-MJB_DEV void tri_rc(const int* tab, int idx, int& r, int& c) {
+template <typename TP> MJB_DEV void tri_rc(TP tab, int idx, int& r, int& c) {
   int v = tab[idx];
   r = v >> 16; c = v & 0xffff;
 }
@@ -233,22 +269,23 @@ MJB_DEV void tri_rc(const int* tab, int idx, int& r, int& c) {
 // ---------------------------------------------------------------------------
 // dense Cholesky in LDS (lower triangle, in place) + solve.  dinv receives 1/L[j][j].
 // ---------------------------------------------------------------------------
-template <typename T, int G> MJB_DEV void chol_factor(T* A, T* dinv, int n, int lane, const int* tri) {
+template <typename T, int G, typename TP> MJB_DEV void chol_factor(T* A, T* dinv, int n, int lane, TP tri) {
+  // A: packed lower triangle (tri_at), factored in place
   for (int j = 0; j < n; j++) {
     gsync<G>();
-    T ajj = A[j * n + j];
+    T ajj = A[tri_at(j, j)];
     T ljj = t_sqrt(t_max(ajj, Num<T>::minval()));
     T inv = 1 / ljj;
     gsync<G>();
-    for (int i = j + 1 + lane; i < n; i += G) A[i * n + j] *= inv;
-    if (lane == 0) { A[j * n + j] = ljj; dinv[j] = inv; }
+    for (int i = j + 1 + lane; i < n; i += G) A[tri_at(i, j)] *= inv;
+    if (lane == 0) { A[tri_at(j, j)] = ljj; dinv[j] = inv; }
     gsync<G>();
     int t = n - 1 - j, np = t * (t + 1) / 2;
     for (int idx = lane; idx < np; idx += G) {
       int r, c;
       tri_rc(tri, idx, r, c);
       int i = j + 1 + r, k = j + 1 + c;
-      A[i * n + k] -= A[i * n + j] * A[k * n + j];
+      A[tri_at(i, k)] -= A[tri_at(i, j)] * A[tri_at(k, j)];
     }
   }
   gsync<G>();
@@ -262,12 +299,12 @@ template <typename T, int G> MJB_DEV void chol_solve(const T* L, const T* dinv, 
     for (int j = 0; j < n; j++) {                       // forward: L y = b
       T xj = gshfl<T, G>(r, j) * dinv[j];
       if (lane == j) r = xj;
-      else if (lane > j && lane < n) r -= L[lane * n + j] * xj;
+      else if (lane > j && lane < n) r -= L[tri_at(lane, j)] * xj;
     }
     for (int j = n - 1; j >= 0; j--) {                  // backward: L^T x = y
       T xj = gshfl<T, G>(r, j) * dinv[j];
       if (lane == j) r = xj;
-      else if (lane < j) r -= L[j * n + lane] * xj;
+      else if (lane < j) r -= L[tri_at(j, lane)] * xj;
     }
     if (lane < n) x[lane] = r;
   } else {
@@ -275,14 +312,14 @@ template <typename T, int G> MJB_DEV void chol_solve(const T* L, const T* dinv, 
       T xj = x[j] * dinv[j];
       gsync<G>();
       if (lane == 0) x[j] = xj;
-      for (int i = j + 1 + lane; i < n; i += G) x[i] -= L[i * n + j] * xj;
+      for (int i = j + 1 + lane; i < n; i += G) x[i] -= L[tri_at(i, j)] * xj;
       gsync<G>();
     }
     for (int j = n - 1; j >= 0; j--) {
       T xj = x[j] * dinv[j];
       gsync<G>();
       if (lane == 0) x[j] = xj;
-      for (int i = lane; i < j; i += G) x[i] -= L[j * n + i] * xj;
+      for (int i = lane; i < j; i += G) x[i] -= L[tri_at(j, i)] * xj;
       gsync<G>();
     }
   }
@@ -365,7 +402,7 @@ MJB_DEV void tile_factor(MRef m, const T* M, T* W, T* dinv, T* col, const T* J, 
 #pragma unroll
     for (int b = 0; b < NB; b++) {
       int r = 8 * a + lr, cc = 8 * b + lc;
-      if (r < n && cc <= r) W[r * n + cc] = e[a][b];
+      if (r < n && cc <= r) W[tri_at(r, cc)] = e[a][b];
     }
   gsync<64>();
 }
@@ -436,9 +473,9 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
   T r = (x && own) ? x[lane] : (T)0;          // fused forward substitution L y = b (b = x on entry)
 #pragma unroll
   for (int j = 0; j < 32; j++) {
-    T ajj = rdlane_f(a[j], j);
-    T ljj = t_sqrt(t_max(ajj, Num<T>::minval()));
-    T inv = 1 / ljj;
+    T ajj = t_max(rdlane_f(a[j], j), Num<T>::minval());
+    T inv = t_rsqrt(ajj);                       // 1/L[j][j]; fp32: v_rsq_f32 + one Newton step
+    T ljj = ajj * inv;
     a[j] = lane == j ? ljj : a[j] * inv;
     if (lane == j) myinv = inv;
     T yj = rdlane_f(r, j) * inv;
@@ -448,14 +485,14 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
   }
   if (own) {
 #pragma unroll
-    for (int k = 0; k < 32; k++) if (k < n) W[lane * n + k] = a[k];
+    for (int k = 0; k < 32; k++) if (k <= lane) W[tri_at(lane, k)] = a[k];
     dinv[lane] = myinv;
   }
   gsync<64>();
   if (x) {                                      // backward substitution L^T x = y: row j of L comes back from LDS
     T lrow[32];
 #pragma unroll
-    for (int j = 0; j < 32; j++) lrow[j] = (j < n && lane < j) ? W[j * n + lane] : (T)0;
+    for (int j = 0; j < 32; j++) lrow[j] = (j < n && lane < j) ? W[tri_at(j, lane)] : (T)0;
 #pragma unroll
     for (int j = 31; j >= 0; j--) {
       T xj = rdlane_f(r, j) * rdlane_f(myinv, j);
@@ -491,7 +528,7 @@ template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
         if (d != 0) h += d * J[r * nv + i] * J[r * nv + k];
       }
     } else if (mode == 2 && i == k) h += m.timestep * m.dof_damping[i];
-    W[i * nv + k] = h;
+    W[tri_at(i, k)] = h;
   }
   gsync<G>();
   chol_factor<T, G>(W, w + L.tmp, nv, lane, m.tri_tab);
@@ -743,16 +780,14 @@ template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
     for (int k = 0; k < 6; k++) buf[6 * i + k] = r[k];
   }
   gsync<G>();
-  int tot = nv << m.nvshift;
-  for (int idx = lane; idx < tot; idx += G) {
-    int i = idx >> m.nvshift, j = idx & (m.nvp - 1);
-    if (j > i || j >= nv) continue;
+  for (int idx = lane; idx < nv * nv; idx += G) M[idx] = 0;
+  gsync<G>();
+  for (int idx = lane; idx < m.nmpair; idx += G) {
+    int pr = m.mpair[idx], i = pr >> 8, j = pr & 0xff;      // j is i or one of its ancestor dofs
     T val = 0;
-    if ((m.dof_ancmask[i] >> j) & 1ull) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) val += cdof[6 * j + k] * buf[6 * i + k];
-      if (i == j) val += m.dof_armature[i];
-    }
+    for (int k = 0; k < 6; k++) val += cdof[6 * j + k] * buf[6 * i + k];
+    if (i == j) val += m.dof_armature[i];
     M[i * nv + j] = val; M[j * nv + i] = val;
   }
   gsync<G>();     // M stays unfactored here: it is factored together with the M^-1 solve in actuation_acceleration
@@ -899,12 +934,11 @@ template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
           T d = dot3(f, f + 3);
           f[3] -= d * f[0]; f[4] -= d * f[1]; f[5] -= d * f[2];
           normalize3(f + 3);
-          cross3(f + 6, f, f + 3);
           T* o = con + slot * CON_STRIDE;
           o[0] = r.dist; o[1] = r.pos[0]; o[2] = r.pos[1]; o[3] = r.pos[2];
 #pragma unroll
-          for (int a = 0; a < 9; a++) o[4 + a] = f[a];
-          o[13] = m.pair_friction[5 * p];
+          for (int a = 0; a < 6; a++) o[4 + a] = f[a];
+          o[10] = m.pair_friction[5 * p];
           con_pair[slot] = p;
         }
       }
@@ -954,7 +988,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
   T *qpos = w + L.qpos, *qvel = w + L.qvel, *J = w + L.efc_J, *epos = w + L.efc_pos, *eD = w + L.efc_D, *earef = w + L.efc_aref;
   T *eK = w + L.efc_jar, *eB = w + L.efc_jv, *eI = w + L.efc_force;       // K, B, imp scratch until aref is known
   T *emargin = w + L.efc_KBI;
-  int *etype = c.wi + L.i_efc_type, *eid = c.wi + L.i_efc_id, *con_pair = c.wi + L.i_con_pair;
+  int *etype = c.wi + L.i_efc_type, *con_pair = c.wi + L.i_con_pair;   // etype: bits 0-7 type, 8 active-at-last-factor, 9.. object id
   T *con = w + L.con, *tl = w + L.ten_length, *tj = w + L.ten_J;
   int nefc = 0, dropped = 0;
   // joint limits, then tendon limits: object `o`, side -1 (lower) then +1 (upper)
@@ -987,8 +1021,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
             T diag = pass == 0 ? m.dof_invweight0[m.jnt_dofadr[o]] : m.tendon_invweight0[o];
             T K, B, imp, R;
             row_params(m, dist[s], margin, sr, si, diag, K, B, imp, R);
-            etype[row] = pass == 0 ? EFC_LIMIT_JOINT : EFC_LIMIT_TENDON;
-            eid[row] = o * 2 + s;
+            etype[row] = (pass == 0 ? EFC_LIMIT_JOINT : EFC_LIMIT_TENDON) | ((o * 2 + s) << 9);
             epos[row] = dist[s]; emargin[row] = margin; eD[row] = 1 / R; eK[row] = K; eB[row] = B; eI[row] = imp;
           }
           row++;
@@ -1000,14 +1033,13 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     }
   }
   if (nefc > cap) nefc = cap;
-  int* con_adr = c.wi + L.i_scal;    // first row of each contact (or -1)
   int nlimit = nefc;
   for (int base = 0; base < c.ncon; base += G) {
     int ci = base + lane, rows = 0, p = 0;
     T dist = 0, mu = 0, incm = 0;
     if (ci < c.ncon) {
-      p = con_pair[ci];
-      dist = con[ci * CON_STRIDE]; mu = con[ci * CON_STRIDE + 13];
+      p = con_pair[ci] & 0xffff;
+      dist = con[ci * CON_STRIDE]; mu = con[ci * CON_STRIDE + 10];
       incm = m.pair_margin[p] - m.pair_gap[p];
       if (dist < incm) rows = m.pair_condim[p] == 1 ? 1 : 4;
     }
@@ -1015,7 +1047,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     int row = nefc + off;
     if (ci < c.ncon) {
       bool fits = rows > 0 && row + rows <= cap;
-      con_adr[ci] = fits ? row : -1;
+      con_pair[ci] = p | ((fits ? row + 1 : 0) << 16);     // bits 16..: first constraint row + 1 (0 = none)
       if (fits) {
         int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
         T tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
@@ -1028,8 +1060,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
           R = t_max(Num<T>::minval(), 2 * mu * mu * R);
         }
         for (int r = 0; r < rows; r++) {
-          etype[row + r] = rows == 1 ? EFC_CONTACT_FRICTIONLESS : EFC_CONTACT_PYRAMIDAL;
-          eid[row + r] = ci;
+          etype[row + r] = (rows == 1 ? EFC_CONTACT_FRICTIONLESS : EFC_CONTACT_PYRAMIDAL) | (ci << 9);
           epos[row + r] = dist; emargin[row + r] = incm; eD[row + r] = 1 / R; eK[row + r] = K; eB[row + r] = B; eI[row + r] = imp;
         }
       }
@@ -1043,8 +1074,8 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     // recompute the true count = last fitting contact's end
     int last = nlimit;
     for (int ci = lane; ci < c.ncon; ci += G) {
-      int a = con_adr[ci];
-      if (a >= 0) { int p = con_pair[ci]; int e = a + (m.pair_condim[p] == 1 ? 1 : 4); if (e > last) last = e; }
+      int a = (con_pair[ci] >> 16) - 1;
+      if (a >= 0) { int p = con_pair[ci] & 0xffff; int e = a + (m.pair_condim[p] == 1 ? 1 : 4); if (e > last) last = e; }
     }
     nefc = gmaxi<G>(last);
   }
@@ -1056,9 +1087,9 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     for (int idx = lane; idx < tot; idx += G) {
       int r = idx >> m.nvshift, i = idx & (m.nvp - 1);
       if (i >= nv) continue;
-      int o = eid[r] >> 1, s = eid[r] & 1;
+      int id_ = etype[r] >> 9, o = id_ >> 1, s = id_ & 1;
       T sign = s == 0 ? (T)1 : (T)-1, v;
-      if (etype[r] == EFC_LIMIT_JOINT) v = (i == m.jnt_dofadr[o]) ? sign : (T)0;
+      if ((etype[r] & 0xff) == EFC_LIMIT_JOINT) v = (i == m.jnt_dofadr[o]) ? sign : (T)0;
       else v = sign * tj[o * nv + i];
       J[r * nv + i] = v;
     }
@@ -1069,9 +1100,9 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     for (int idx = lane; idx < tot; idx += G) {
       int ci = idx >> m.nvshift, i = idx & (m.nvp - 1);
       if (i >= nv) continue;
-      int row = con_adr[ci];
+      int row = (con_pair[ci] >> 16) - 1;
       if (row < 0) continue;
-      int p = con_pair[ci];
+      int p = con_pair[ci] & 0xffff;
       int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
       const T* cc = con + ci * CON_STRIDE;
       T pos[3] = {cc[1], cc[2], cc[3]}, j1[3], j2[3], dj[3];
@@ -1081,8 +1112,9 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
       T jn = cc[4] * dj[0] + cc[5] * dj[1] + cc[6] * dj[2];
       if (m.pair_condim[p] == 1) J[row * nv + i] = jn;
       else {
-        T mu = cc[13];
-        T jt1 = mu * (cc[7] * dj[0] + cc[8] * dj[1] + cc[9] * dj[2]), jt2 = mu * (cc[10] * dj[0] + cc[11] * dj[1] + cc[12] * dj[2]);
+        T mu = cc[10], nrm[3] = {cc[4], cc[5], cc[6]}, t1[3] = {cc[7], cc[8], cc[9]}, t2[3];
+        cross3(t2, nrm, t1);
+        T jt1 = mu * dot3(t1, dj), jt2 = mu * dot3(t2, dj);
         J[row * nv + i] = jn + jt1; J[(row + 1) * nv + i] = jn - jt1;
         J[(row + 2) * nv + i] = jn + jt2; J[(row + 3) * nv + i] = jn - jt2;
       }
@@ -1090,9 +1122,11 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
   }
   gsync<G>();
   // reference acceleration: aref = -B (J qvel) - K imp (pos - margin)
+  const VecBcast<T, G> xv(qvel, nv, lane);
   for (int r = lane; r < nefc; r += G) {
     T v = 0;
-    for (int i = 0; i < nv; i++) v += J[r * nv + i] * qvel[i];
+#pragma unroll 4
+    for (int i = 0; i < nv; i++) v += J[r * nv + i] * xv.get(i);
     earef[r] = -eB[r] * v - eK[r] * eI[r] * (epos[r] - emargin[r]);
   }
   gsync<G>();
@@ -1279,23 +1313,19 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
   T *sx = w + L.site_xpos, *sm = w + L.site_xmat;
   for (int i = lane; i < nv; i += G) {
     T s = 0;
-    for (int a = 0; a < m.nu; a++) {
-      int id = m.actuator_trnid[2 * a];
-      if (m.actuator_trntype[a] == TRN_JOINT) {
-        if (m.jnt_dofadr[id] == i) s += m.actuator_gear[6 * a] * af[a];
-      } else {
-        int b = m.site_bodyid[id];
-        if (!((m.body_dofmask[b] >> i) & 1ull)) continue;
-        T g[6], R[9], f[3], tq[3], pt[3] = {sx[3 * id], sx[3 * id + 1], sx[3 * id + 2]}, jp[3], jr[3];
+    for (int k = m.dofact_adr[i]; k < m.dofact_adr[i + 1]; k++) { int a = m.dofact_act[k]; s += m.actuator_gear[6 * a] * af[a]; }
+    for (int k = 0; k < m.nsiteact; k++) {
+      int a = m.siteact[k], id = m.actuator_trnid[2 * a], b = m.site_bodyid[id];
+      if (!((m.body_dofmask[b] >> i) & 1ull)) continue;
+      T g[6], R[9], f[3], tq[3], pt[3] = {sx[3 * id], sx[3 * id + 1], sx[3 * id + 2]}, jp[3], jr[3];
 #pragma unroll
-        for (int k = 0; k < 6; k++) g[k] = m.actuator_gear[6 * a + k];
+      for (int q = 0; q < 6; q++) g[q] = m.actuator_gear[6 * a + q];
 #pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = sm[9 * id + k];
-        mulmatvec3(f, R, g);
-        mulmatvec3(tq, R, g + 3);
-        jac_col<T>(c, b, i, pt, jp, jr);
-        s += (dot3(jp, f) + dot3(jr, tq)) * af[a];
-      }
+      for (int q = 0; q < 9; q++) R[q] = sm[9 * id + q];
+      mulmatvec3(f, R, g);
+      mulmatvec3(tq, R, g + 3);
+      jac_col<T>(c, b, i, pt, jp, jr);
+      s += (dot3(jp, f) + dot3(jr, tq)) * af[a];
     }
     qa[i] = s;
     T fs = qp[i] - qb[i] + s;
@@ -1314,15 +1344,18 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *aref = w + L.efc_aref, *D = w + L.efc_D, *force = w + L.efc_force;
   T *qs = w + L.qfrc_smooth, *qas = w + L.qacc_smooth;
   T part = 0;
+  const VecBcast<T, G> xq(qacc, nv, lane);
   for (int i = lane; i < nv; i += G) {
     T s = 0;
-    for (int k = 0; k < nv; k++) s += M[i * nv + k] * qacc[k];
+#pragma unroll 4
+    for (int k = 0; k < nv; k++) s += M[i * nv + k] * xq.get(k);
     Ma[i] = s;
     part += (T)0.5 * (s - qs[i]) * (qacc[i] - qas[i]);
   }
   for (int r = lane; r < nefc; r += G) {
     T s = -aref[r];
-    for (int k = 0; k < nv; k++) s += J[r * nv + k] * qacc[k];
+#pragma unroll 4
+    for (int k = 0; k < nv; k++) s += J[r * nv + k] * xq.get(k);
     jar[r] = s;
     if (s < 0) { part += (T)0.5 * D[r] * s * s; if (store) force[r] = -D[r] * s; }
     else if (store) force[r] = 0;
@@ -1343,12 +1376,13 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first) {
   for (int r = lane; r < nefc; r += G) {
     int act = jar[r] < 0 ? 1 : 0, t = etype[r];
     if (((t >> 8) & 1) != act) chg = 1;
-    etype[r] = (t & 0xff) | (act << 8);
+    etype[r] = (t & ~0x100) | (act << 8);
     dw[r] = act ? D[r] : (T)0;
   }
   T gpart = 0;
   for (int i = lane; i < nv; i += G) {
     T g = Ma[i] - qs[i];
+#pragma unroll 4
     for (int r = 0; r < nefc; r++) g -= J[r * nv + i] * force[r];
     grad[i] = g; search[i] = g;
     gpart += g * g;
@@ -1394,15 +1428,18 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     if (scale * t_sqrt(gn) < m.tolerance) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
+    const VecBcast<T, G> xs(search, nv, lane);
     for (int i = lane; i < nv; i += G) {
       T sacc = 0;
-      for (int k = 0; k < nv; k++) sacc += M[i * nv + k] * search[k];
+#pragma unroll 4
+      for (int k = 0; k < nv; k++) sacc += M[i * nv + k] * xs.get(k);
       Mv[i] = sacc;
       p1 += search[i] * (Ma[i] - qs[i]); p2 += search[i] * sacc;
     }
     for (int r = lane; r < nefc; r += G) {
       T sacc = 0;
-      for (int k = 0; k < nv; k++) sacc += J[r * nv + k] * search[k];
+#pragma unroll 4
+      for (int k = 0; k < nv; k++) sacc += J[r * nv + k] * xs.get(k);
       jv[r] = sacc;
     }
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
@@ -1446,6 +1483,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   }
   for (int i = lane; i < nv; i += G) {
     T sacc = 0;
+#pragma unroll 4
     for (int r = 0; r < nefc; r++) sacc += J[r * nv + i] * force[r];
     qc[i] = sacc; ws[i] = qacc[i];
   }
@@ -1459,8 +1497,8 @@ template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
   MJB_STAMP(c, PH_OTHER);
   kinematics<T, G>(c); MJB_STAMP(c, PH_KIN);
   com_pos<T, G>(c); MJB_STAMP(c, PH_COM);
-  crb_factor<T, G>(c); MJB_STAMP(c, PH_CRB);
   collision<T, G>(c); MJB_STAMP(c, PH_COLL);
+  crb_factor<T, G>(c); MJB_STAMP(c, PH_CRB);
   make_constraint<T, G>(c); MJB_STAMP(c, PH_CONS);
   vel_bias_passive<T, G>(c); MJB_STAMP(c, PH_VEL);
   actuation_acceleration<T, G>(c); MJB_STAMP(c, PH_ACT);

@@ -48,7 +48,7 @@ struct HostModel {
   double timestep = 0, gravity[3] = {0, 0, 0}, density = 0, viscosity = 0, tolerance = 1e-8, meaninertia = 1;
   std::vector<std::pair<std::string, std::vector<double>>> fd;
   std::vector<std::pair<std::string, std::vector<int>>> id;
-  std::vector<int> level_adr, level_body, child_adr, child_id, tri_tab;
+  std::vector<int> level_adr, level_body, child_adr, child_id, tri_tab, dofact_adr, dofact_act, siteact, mpair;
   std::vector<unsigned long long> body_dofmask, dof_ancmask;
 
   const std::vector<double>& D(const char* k) const {
@@ -72,6 +72,7 @@ struct HostModel {
     if (!t.getd("gravity", 3, dv, err)) return false;
     gravity[0] = dv[0]; gravity[1] = dv[1]; gravity[2] = dv[2];
     if (nv > 64) { err = "nv > 64 is outside the supported subset (dof masks are 64-bit)"; return false; }
+    if (npair > 65535) { err = "more than 65535 collision pairs is outside the supported subset"; return false; }
     struct FD { const char* k; long c; };
     const FD fds[] = {
       {"body_pos", nbody * 3L}, {"body_quat", nbody * 4L}, {"body_ipos", nbody * 3L}, {"body_iquat", nbody * 4L}, {"body_mass", nbody},
@@ -132,6 +133,18 @@ struct HostModel {
     for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = dofpar[j]) dof_ancmask[i] |= 1ull << j;
     tri_tab.clear();
     for (int r = 0; r < (nv > 0 ? nv : 1); r++) for (int cc = 0; cc <= r; cc++) tri_tab.push_back((r << 16) | cc);
+    {  // actuators grouped by the dof they drive (joint transmission) / list of site transmissions
+      const auto& trntype = I("actuator_trntype"); const auto& trnid = I("actuator_trnid"); const auto& jdof = I("jnt_dofadr");
+      dofact_adr.assign(nv + 1, 0); dofact_act.clear(); siteact.clear();
+      for (int i = 0; i < nv; i++) {
+        dofact_adr[i] = (int)dofact_act.size();
+        for (int a = 0; a < nu; a++) if (trntype[a] == TRN_JOINT && jdof[trnid[2 * a]] == i) dofact_act.push_back(a);
+      }
+      dofact_adr[nv] = (int)dofact_act.size();
+      for (int a = 0; a < nu; a++) if (trntype[a] != TRN_JOINT) siteact.push_back(a);
+      mpair.clear();
+      for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = dofpar[j]) mpair.push_back((i << 8) | j);
+    }
     has_damping = 0;
     for (double v : D("dof_damping")) if (v > 0) has_damping = 1;
     has_fluid = (density > 0 || viscosity > 0) ? 1 : 0;
@@ -157,7 +170,7 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   m.ntendon = h.ntendon; m.nwrap = h.nwrap; m.nsensor = h.nsensor; m.nsensordata = h.nsensordata; m.nkey = h.nkey; m.npair = h.npair;
   m.nlevel = h.nlevel; m.integrator = h.integrator; m.disableactuator = h.disableactuator; m.iterations = h.iterations;
   m.has_damping = h.has_damping; m.has_fluid = h.has_fluid; m.nvp = h.nvp; m.nvshift = h.nvshift;
-  m.ncon_max = ncon_max; m.nefc_max = nefc_max;
+  m.ncon_max = ncon_max; m.nefc_max = nefc_max; m.nsiteact = (int)h.siteact.size(); m.nmpair = (int)h.mpair.size();
   m.timestep = (T)h.timestep; m.gravity[0] = (T)h.gravity[0]; m.gravity[1] = (T)h.gravity[1]; m.gravity[2] = (T)h.gravity[2];
   m.density = (T)h.density; m.viscosity = (T)h.viscosity; m.meaninertia = (T)h.meaninertia;
   // fp32 cannot resolve MuJoCo's 1e-8 scaled tolerance; floor it at what single precision supports
@@ -175,6 +188,7 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   m.body_parentid = Iq("body_parentid"); m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
   m.body_dofadr = Iq("body_dofadr"); m.body_dofnum = Iq("body_dofnum");
   m.level_adr = (IP)alloc.puti(h.level_adr); m.level_body = (IP)alloc.puti(h.level_body); m.child_adr = (IP)alloc.puti(h.child_adr); m.child_id = (IP)alloc.puti(h.child_id); m.tri_tab = (IP)alloc.puti(h.tri_tab);
+  m.dofact_adr = (IP)alloc.puti(h.dofact_adr); m.dofact_act = (IP)alloc.puti(h.dofact_act); m.siteact = (IP)alloc.puti(h.siteact); m.mpair = (IP)alloc.puti(h.mpair);
   m.body_pos = F("body_pos"); m.body_quat = F("body_quat"); m.body_ipos = F("body_ipos"); m.body_iquat = F("body_iquat"); m.body_mass = F("body_mass");
   m.body_inertia = F("body_inertia"); m.body_subtreemass = F("body_subtreemass"); m.body_invweight0 = F("body_invweight0");
   m.body_dofmask = (UP)alloc.putu(h.body_dofmask); m.dof_ancmask = (UP)alloc.putu(h.dof_ancmask);
@@ -206,20 +220,36 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   int nq = h.nq, nv = h.nv, nu = h.nu, nb = h.nbody, nj = h.njnt, ng = h.ngeom, ns = h.nsite, nt = h.ntendon;
   L.qpos = A(nq); L.qvel = A(nv); L.ctrl = A(nu); L.qacc = A(nv); L.qacc_ws = A(nv); L.qacc_smooth = A(nv);
   L.qfrc_bias = A(nv); L.qfrc_passive = A(nv); L.qfrc_actuator = A(nv); L.qfrc_smooth = A(nv); L.qfrc_constraint = A(nv);
-  L.xpos = A(3 * nb); L.xquat = A(4 * nb); L.xmat = A(9 * nb); L.xipos = A(3 * nb); L.ximat = A(9 * nb);
-  L.xanchor = A(3 * nj); L.xaxis = A(3 * nj); L.geom_xpos = A(3 * ng); L.geom_xmat = A(9 * ng); L.site_xpos = A(3 * ns); L.site_xmat = A(9 * ns);
-  L.subtree_com = A(3 * nb); L.cinert = A(10 * nb); L.crb = A(10 * nb); L.cdof = A(6 * nv); L.cdof_dot = A(6 * nv);
-  L.cvel = A(6 * nb); L.cacc = A(6 * nb); L.cfrc = A(6 * nb); L.dofbuf = A(6 * nv); L.bfrc = A(h.has_fluid ? 6 * nb : 0);
-  L.M = A(nv * nv); L.W = A(nv * nv); L.ten_length = A(nt); L.ten_J = A(nt * nv); L.act_force = A(nu);
+  L.xpos = A(3 * nb); L.xquat = A(4 * nb); L.xipos = A(3 * nb); L.ximat = A(9 * nb);
+  L.geom_xpos = A(3 * ng); L.site_xpos = A(3 * ns); L.site_xmat = A(9 * ns);
+  L.subtree_com = A(3 * nb); L.cinert = A(10 * nb); L.cdof = A(6 * nv); L.cvel = A(6 * nb); L.bfrc = A(h.has_fluid ? 6 * nb : 0);
+  L.M = A(nv * nv); L.W = A(nv * (nv + 1) / 2); L.ten_length = A(nt); L.ten_J = A(nt * nv); L.act_force = A(nu);
   L.con = A(ncon_max * CON_STRIDE);
-  L.efc_J = A(nefc_max * nv); L.efc_pos = A(nefc_max); L.efc_D = A(nefc_max); L.efc_aref = A(nefc_max); L.efc_jar = A(nefc_max);
-  L.efc_jv = A(nefc_max); L.efc_force = A(nefc_max); L.efc_KBI = A(nefc_max);
-  L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.tmp = A(nv); L.cholcol = A(nv + 1);
+  L.efc_J = A(nefc_max * nv); L.efc_pos = A(nefc_max); L.efc_D = A(nefc_max); L.efc_aref = A(nefc_max);
+  L.tmp = A(nv);
+  // One overlay region for temporaries with disjoint lifetimes (forward() order: kinematics, com_pos, collision,
+  // crb, make_constraint, velocity stage, actuation, solver):
+  //   g1 (kinematics .. collision):  xmat, xanchor, xaxis, geom_xmat
+  //   g2 (crb):                      crb, dofbuf
+  //   g3 (make_constraint):          K, B, imp in jar / jv / force, margins in efc_KBI
+  //   g4 (velocity stage):           cdof_dot, cacc, cfrc
+  //   g5 (solver .. integrator):     Ma, grad, search, Mv, cholcol, jar, jv, force
+  int r0 = o, rend = o;
+  L.xmat = A(9 * nb); L.xanchor = A(3 * nj); L.xaxis = A(3 * nj); L.geom_xmat = A(9 * ng);
+  if (o > rend) rend = o; o = r0;
+  L.crb = A(10 * nb); L.dofbuf = A(6 * nv);
+  if (o > rend) rend = o; o = r0;
+  L.cdof_dot = A(6 * nv); L.cacc = A(6 * nb); L.cfrc = A(6 * nb);
+  if (o > rend) rend = o; o = r0;
+  L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.cholcol = A(nv + 1);
+  L.efc_jar = A(nefc_max); L.efc_jv = A(nefc_max); L.efc_force = A(nefc_max); L.efc_KBI = A(nefc_max);
+  if (o > rend) rend = o;
+  o = rend;
   L.rk = A(h.integrator == INT_RK4 ? nq + nv + 8 * nv + nv : 0);
   L.nT = o;
   int oi = 0;
   auto AI = [&](int n) { int r = oi; oi += n > 0 ? n : 0; return r; };
-  L.i_efc_type = AI(nefc_max); L.i_efc_id = AI(nefc_max); L.i_con_pair = AI(ncon_max); L.i_scal = AI(ncon_max);
+  L.i_efc_type = AI(nefc_max); L.i_efc_id = L.i_efc_type; L.i_con_pair = AI(ncon_max); L.i_scal = L.i_con_pair;   // ids are packed into the same words
   L.nI = oi;
   size_t bytes = (size_t)L.nT * sizeofT + (size_t)L.nI * sizeof(int);
   L.bytes = (int)((bytes + 15) / 16 * 16);

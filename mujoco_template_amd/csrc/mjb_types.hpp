@@ -36,11 +36,12 @@ struct DevModel {
   typedef const unsigned long long MJB_CONST* UP;    // 64-bit dof mask table
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nsensor, nsensordata, nkey, npair;
   int nlevel, integrator, disableactuator, iterations, has_damping, has_fluid, nvp, nvshift;
-  int ncon_max, nefc_max;
+  int ncon_max, nefc_max, nsiteact, nmpair;
   T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
   // kinematic tree
   IP body_parentid, body_rootid, body_jntadr, body_jntnum, body_dofadr, body_dofnum;
   IP level_adr, level_body, child_adr, child_id, tri_tab;
+  IP dofact_adr, dofact_act, siteact, mpair;   // joint-transmission actuators per dof (CSR), site-transmission actuators, (i<<8|j) ancestor dof pairs of M
   FP body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_subtreemass, body_invweight0;
   UP body_dofmask, dof_ancmask;
   // joints / dofs
@@ -87,7 +88,7 @@ struct Lay {
   int bytes;          // total bytes per environment (rounded to 16)
 };
 
-constexpr int CON_STRIDE = 14;  // dist, pos[3], frame[9], mu(friction[0]) ; pair id in i_con_pair
+constexpr int CON_STRIDE = 11;  // dist, pos[3], normal[3], tangent1[3], mu (friction[0]); tangent2 = n x t1; pair id in i_con_pair
 
 // Device state of the batch (TS = storage type of the [batch, dof] arrays in HBM).
 template <typename TS>

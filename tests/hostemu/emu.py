@@ -56,7 +56,7 @@ class EmuEnv:
             "qacc_smooth": np.zeros(nv), "qfrc_constraint": np.zeros(nv),
             "efc_J": np.zeros(self.nefc_max * nv), "efc_aref": np.zeros(self.nefc_max), "efc_D": np.zeros(self.nefc_max),
             "efc_pos": np.zeros(self.nefc_max), "efc_force": np.zeros(self.nefc_max), "efc_type": np.zeros(self.nefc_max, dtype=np.int32),
-            "con": np.zeros(self.ncon_max * 14), "cdof": np.zeros(6 * nv), "cinert": np.zeros(10 * m.nbody), "cvel": np.zeros(6 * m.nbody),
+            "con": np.zeros(self.ncon_max * 11), "cdof": np.zeros(6 * nv), "cinert": np.zeros(10 * m.nbody), "cvel": np.zeros(6 * m.nbody),
         }
 
     def __getattr__(self, k):
