@@ -116,6 +116,22 @@ template <typename T, int G> struct VecBcast {
   }
 };
 
+// sum_k a[k*stride] * x(k), k < n, manually unrolled by 8 (independent LDS reads in flight; v_readlane is a
+// convergent operation, so the compiler will not unroll such loops by itself)
+template <typename T, typename X> MJB_DEV T dot_lds(const T* a, int stride, const X& x, int n) {
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    const T* p = a + k * stride;
+    T a0 = p[0], a1 = p[stride], a2 = p[2 * stride], a3 = p[3 * stride], a4 = p[4 * stride], a5 = p[5 * stride], a6 = p[6 * stride], a7 = p[7 * stride];
+    s0 += a0 * x.get(k); s1 += a1 * x.get(k + 1); s2 += a2 * x.get(k + 2); s3 += a3 * x.get(k + 3);
+    s0 += a4 * x.get(k + 4); s1 += a5 * x.get(k + 5); s2 += a6 * x.get(k + 6); s3 += a7 * x.get(k + 7);
+  }
+  for (; k < n; k++) s0 += a[k * stride] * x.get(k);
+  return (s0 + s1) + (s2 + s3);
+}
+template <typename T> struct VecLds { const T* x; MJB_DEVM T get(int k) const { return x[k]; } };
+
 #define MJB_MINIMP ((T)0.0001)
 #define MJB_MAXIMP ((T)0.9999)
 #define MJB_PI ((T)3.14159265358979323846)
@@ -1124,9 +1140,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
   // reference acceleration: aref = -B (J qvel) - K imp (pos - margin)
   const VecBcast<T, G> xv(qvel, nv, lane);
   for (int r = lane; r < nefc; r += G) {
-    T v = 0;
-#pragma unroll 4
-    for (int i = 0; i < nv; i++) v += J[r * nv + i] * xv.get(i);
+    T v = dot_lds(J + r * nv, 1, xv, nv);
     earef[r] = -eB[r] * v - eK[r] * eI[r] * (epos[r] - emargin[r]);
   }
   gsync<G>();
@@ -1346,16 +1360,12 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   T part = 0;
   const VecBcast<T, G> xq(qacc, nv, lane);
   for (int i = lane; i < nv; i += G) {
-    T s = 0;
-#pragma unroll 4
-    for (int k = 0; k < nv; k++) s += M[i * nv + k] * xq.get(k);
+    T s = dot_lds(M + i * nv, 1, xq, nv);
     Ma[i] = s;
     part += (T)0.5 * (s - qs[i]) * (qacc[i] - qas[i]);
   }
   for (int r = lane; r < nefc; r += G) {
-    T s = -aref[r];
-#pragma unroll 4
-    for (int k = 0; k < nv; k++) s += J[r * nv + k] * xq.get(k);
+    T s = dot_lds(J + r * nv, 1, xq, nv) - aref[r];
     jar[r] = s;
     if (s < 0) { part += (T)0.5 * D[r] * s * s; if (store) force[r] = -D[r] * s; }
     else if (store) force[r] = 0;
@@ -1365,8 +1375,9 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   return cost;
 }
 
-template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first) {
-  // grad, H = M + J^T D_active J (lower, Cholesky in W), search = -H^-1 grad.  Returns |grad|^2.
+template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T gtol2) {
+  // grad, H = M + J^T D_active J (lower, Cholesky in W), search = -H^-1 grad.  Returns |grad|^2; when that is
+  // already below gtol2 the (expensive) factorisation is skipped — the caller stops iterating.
   // The factor is rebuilt only when the active set changed since the last build (bit 8 of efc_type remembers it).
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
   T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *D = w + L.efc_D, *force = w + L.efc_force;
@@ -1381,15 +1392,17 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first) {
   }
   T gpart = 0;
   for (int i = lane; i < nv; i += G) {
-    T g = Ma[i] - qs[i];
-#pragma unroll 4
-    for (int r = 0; r < nefc; r++) g -= J[r * nv + i] * force[r];
+    T g = Ma[i] - qs[i] - dot_lds(J + i, nv, VecLds<T>{force}, nefc);
     grad[i] = g; search[i] = g;
     gpart += g * g;
   }
   T gn = gsum<T, G>(gpart);
   const bool rebuild = gsumi<G>(chg) != 0;
   gsync<G>();
+  if (gn < gtol2) return gn;
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+  c.pacc[13] += 1; if (rebuild) c.pacc[14] += 1;
+#endif
   if (rebuild) factor_W<T, G>(c, 1, search);
   else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
   for (int i = lane; i < nv; i += G) search[i] = -search[i];
@@ -1423,27 +1436,24 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
   for (int iter = 0; iter < m.iterations; iter++) {
     MJB_STAMP(c, PH_SOLVE);
-    T gn = newton_direction<T, G>(c, iter == 0);
+    const T gtol = m.tolerance / scale;
+    T gn = newton_direction<T, G>(c, iter == 0, gtol * gtol);
     MJB_STAMP(c, PH_SOL_DIR);
-    if (scale * t_sqrt(gn) < m.tolerance) break;
+    if (gn < gtol * gtol) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
     const VecBcast<T, G> xs(search, nv, lane);
     for (int i = lane; i < nv; i += G) {
-      T sacc = 0;
-#pragma unroll 4
-      for (int k = 0; k < nv; k++) sacc += M[i * nv + k] * xs.get(k);
+      T sacc = dot_lds(M + i * nv, 1, xs, nv);
       Mv[i] = sacc;
       p1 += search[i] * (Ma[i] - qs[i]); p2 += search[i] * sacc;
     }
     for (int r = lane; r < nefc; r += G) {
-      T sacc = 0;
-#pragma unroll 4
-      for (int k = 0; k < nv; k++) sacc += J[r * nv + k] * xs.get(k);
-      jv[r] = sacc;
+      jv[r] = dot_lds(J + r * nv, 1, xs, nv);
     }
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
     gsync<G>();
+    MJB_STAMP(c, 15);
     // exact line search on the convex piecewise-quadratic: safeguarded Newton on the derivative
     T alpha = 0, lo = 0, hi = -1;
     for (int it = 0; it < 50; it++) {
@@ -1461,6 +1471,9 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
       if (an <= lo || (hi >= 0 && an >= hi)) an = hi >= 0 ? (T)0.5 * (lo + hi) : 2 * alpha + (T)1e-3;
       if (an == alpha) break;
       alpha = an;
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+      c.pacc[12] += 1;
+#endif
     }
     MJB_STAMP(c, PH_SOL_LS);
     if (alpha == 0) break;
@@ -1482,10 +1495,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     if (scale * (old - cost) < m.tolerance) break;
   }
   for (int i = lane; i < nv; i += G) {
-    T sacc = 0;
-#pragma unroll 4
-    for (int r = 0; r < nefc; r++) sacc += J[r * nv + i] * force[r];
-    qc[i] = sacc; ws[i] = qacc[i];
+    qc[i] = dot_lds(J + i, nv, VecLds<T>{force}, nefc); ws[i] = qacc[i];
   }
   gsync<G>();
 }

@@ -13,7 +13,9 @@ n = 100
 sim.rollout(n, CTRL_RANDOM, seed=1, step0=50); sim.sync()
 p = sim.profile_get().astype(float) / (B * n)
 names = ["kinematics", "com_pos", "crb+factorM", "collision", "constraints", "vel/bias/passive", "actuation+Msolve", "solver(rest)", "integrate(euler)", "other", "solver:direction(H,chol,solve)", "solver:linesearch"]
-tot = p.sum()
+tot = p[:12].sum() + p[15]
 print(f"B={B}: cycles per env-step {tot:.0f}")
 for k, nm in enumerate(names):
     print(f"  {nm:34s} {p[k]:9.0f}  {100*p[k]/tot:5.1f}%")
+print(f"  {'solver:Mv,jv products':34s} {p[15]:9.0f}  {100*p[15]/tot:5.1f}%")
+print(f"  per env-step: line-search iterations {p[12]:.2f}, Newton directions {p[13]:.2f}, Hessian factorisations {p[14]:.2f}")
