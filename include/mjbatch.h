@@ -36,6 +36,8 @@ typedef struct mjbObsSpec mjbObsSpec;
 #define MJB_CTRL_KEEP 0    /* use data.ctrl as is (host controller wrote it)  */
 #define MJB_CTRL_ZERO 1    /* ZeroController, reference controllers.py:12-25 */
 #define MJB_CTRL_RANDOM 2  /* uniform random ctrl, Philox(seed; env, step, actuator) */
+#define MJB_CTRL_FEEDBACK 3 /* ctrl = clip(u0 - K [q (-) q0; qvel - v0]): the LQR law of the reference's examples
+                               (examples/humanoid/controllers/lqr.py:147-170), gains set by mjb_set_feedback */
 
 const char* mjb_last_error(void);
 int mjb_device_count(void);
@@ -80,6 +82,9 @@ int mjb_step(mjbData* d, int nstep);
  * `obs_every`-th step is written to obs_out_dev[(nstep/obs_every), batch, dim] (dtype of the data). */
 int mjb_rollout(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned step0, double ctrl_scale,
                 const mjbObsSpec* spec, void* obs_out_dev, int obs_every);
+
+/* gains of MJB_CTRL_FEEDBACK, host float64: K [nu, 2nv] row-major, u0 [nu], q0 [nq], v0 [nv] (NULL = zeros); shared by all environments */
+int mjb_set_feedback(mjbData* d, const double* K, const double* u0, const double* q0, const double* v0);
 
 /* ---- observations: ObservationExtractor.__call__ with as_dict=False (reference observations.py:98-174) ---- */
 int mjb_obs_spec_create(mjbData* d, int flags, int nsite, const int* site_ids, int nbody, const int* body_ids,

@@ -14,7 +14,7 @@ from . import mj
 from ._typing import InfoDict, JacobianDict, JacobiansDict, Observation, ObservationArray, ObservationDict, StateSnapshot
 from .compat import CompatibilityReport, check_controller_compat
 from .control import ControlSpace, Controller, ControllerCapabilities
-from .controllers import PositionTargetDemo, RandomCtrlController, ZeroController
+from .controllers import LinearFeedbackController, PositionTargetDemo, RandomCtrlController, ZeroController
 from .env import Env, StepResult
 from .exceptions import CompatibilityError, ConfigError, LinearizationError, NameLookupError, TemplateError
 from .jacobians import compute_requested_jacobians
@@ -29,7 +29,7 @@ __all__ = [
     "mj", "TemplateError", "NameLookupError", "CompatibilityError", "LinearizationError", "ConfigError",
     "ControlSpace", "Controller", "ControllerCapabilities", "ObservationSpec", "ObservationExtractor",
     "ObservationProducer", "ModelHandle", "CompatibilityReport", "StepResult", "Env", "ZeroController",
-    "PositionTargetDemo", "RandomCtrlController", "check_controller_compat", "linearize_discrete",
+    "PositionTargetDemo", "RandomCtrlController", "LinearFeedbackController", "check_controller_compat", "linearize_discrete",
     "compute_requested_jacobians", "StepHook", "iterate_passive", "run_passive_headless", "ObservationDict",
     "ObservationArray", "Observation", "JacobianDict", "JacobiansDict", "InfoDict", "StateSnapshot", "__version__",
 ]

@@ -23,7 +23,7 @@ _LIB_PATH = os.path.join(_HERE, "libmjbatch_prof.so" if os.environ.get("MJB_PROF
 _LIB: ctypes.CDLL | None = None
 
 MJB_F32, MJB_F64 = 0, 1
-CTRL_KEEP, CTRL_ZERO, CTRL_RANDOM = 0, 1, 2
+CTRL_KEEP, CTRL_ZERO, CTRL_RANDOM, CTRL_FEEDBACK = 0, 1, 2, 3
 COUNTER_NAMES = ("ncon", "nefc", "solver_niter", "con_dropped", "efc_dropped", "warn_badqpos", "warn_badqvel", "warn_badqacc")
 
 
@@ -70,6 +70,8 @@ def load_library() -> ctypes.CDLL:
     L.mjb_forward.argtypes = [vp]
     L.mjb_step.argtypes = [vp, ci]
     L.mjb_rollout.argtypes = [vp, ci, ci, cu, cu, cd, vp, vp, ci]
+    L.mjb_set_feedback.argtypes = [vp, vp, vp, vp, vp]
+    L.mjb_set_feedback.restype = ci
     L.mjb_obs_spec_create.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci, vp, pvp]
     L.mjb_obs_spec_free.argtypes = [vp]
     L.mjb_obs_dim.argtypes = [vp]
@@ -242,6 +244,16 @@ class BatchSim:
                                           float(ctrl_scale), obs_spec.ptr if obs_spec else None,
                                           ctypes.c_void_p(obs_out_ptr) if obs_out_ptr else None, int(obs_every)))
 
+    def set_feedback(self, K: np.ndarray, u0: np.ndarray, q0: np.ndarray, v0: np.ndarray | None = None) -> None:
+        m = self.model.compiled
+        K = np.ascontiguousarray(K, dtype=np.float64)
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        v0 = np.zeros(m.nv) if v0 is None else np.ascontiguousarray(v0, dtype=np.float64)
+        if K.shape != (m.nu, 2 * m.nv) or u0.shape != (m.nu,) or q0.shape != (m.nq,) or v0.shape != (m.nv,):
+            raise ConfigError("feedback gains must have shapes K [nu, 2nv], u0 [nu], q0 [nq], v0 [nv]")
+        _check(load_library().mjb_set_feedback(self.ptr, K.ctypes.data, u0.ctypes.data, q0.ctypes.data, v0.ctypes.data))
+
     def make_obs_spec(self, flags: int, site_ids=(), body_ids=(), geom_ids=(), subtree_ids=()) -> ObsSpecHandle:
         return ObsSpecHandle(self, flags, site_ids, body_ids, geom_ids, subtree_ids)
 
@@ -292,4 +304,4 @@ class BatchSim:
             pass
 
 
-__all__ = ["BatchSim", "DeviceModel", "ObsSpecHandle", "build_library", "load_library", "CTRL_KEEP", "CTRL_ZERO", "CTRL_RANDOM"]
+__all__ = ["BatchSim", "DeviceModel", "ObsSpecHandle", "build_library", "load_library", "CTRL_KEEP", "CTRL_ZERO", "CTRL_RANDOM", "CTRL_FEEDBACK"]

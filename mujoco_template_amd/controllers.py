@@ -105,4 +105,40 @@ class RandomCtrlController:
         self.step_count += 1
 
 
-__all__ = ["ZeroController", "PositionTargetDemo", "RandomCtrlController", "philox_uniform"]
+@dataclass
+class LinearFeedbackController:
+    """``ctrl = clip(ctrl0 - K [q (-) q_goal ; qvel - qvel_goal])`` — the LQR feedback law of the reference's
+    examples (``examples/humanoid/controllers/lqr.py:147-170``, ``examples/drone2/main.py:400-471``), evaluated
+    inside the fused rollout kernel (``device_ctrl_mode = "feedback"``).  ``__call__`` is the same law on the host."""
+
+    K: np.ndarray = None            # [nu, 2 nv]
+    ctrl0: np.ndarray = None        # [nu]
+    qpos_goal: np.ndarray = None    # [nq]
+    qvel_goal: np.ndarray | None = None
+    capabilities: ControllerCapabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
+    device_ctrl_mode: str = "feedback"
+
+    def prepare(self, model: Any, data: Any) -> None:
+        if model.nu == 0:
+            raise CompatibilityError("LinearFeedbackController requires nu>0.")
+        self.K = np.asarray(self.K, dtype=float)
+        self.ctrl0 = np.asarray(self.ctrl0, dtype=float)
+        self.qpos_goal = np.asarray(self.qpos_goal, dtype=float)
+        self.qvel_goal = np.zeros(model.nv) if self.qvel_goal is None else np.asarray(self.qvel_goal, dtype=float)
+        if self.K.shape != (model.nu, 2 * model.nv) or self.ctrl0.shape != (model.nu,) or self.qpos_goal.shape != (model.nq,):
+            raise ConfigError("LinearFeedbackController: K must be [nu, 2nv], ctrl0 [nu], qpos_goal [nq]")
+
+    def __call__(self, model: Any, data: Any, t: float) -> None:
+        from . import mj
+
+        rows, qpos, qvel = _ctrl_rows(data), np.atleast_2d(data.qpos), np.atleast_2d(data.qvel)
+        lo = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 0], -np.inf)
+        hi = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 1], np.inf)
+        dq = np.zeros(model.nv)
+        for e in range(rows.shape[0]):
+            mj.mj_differentiatePos(model, dq, 1.0, self.qpos_goal, qpos[e])
+            dx = np.concatenate([dq, qvel[e] - self.qvel_goal])
+            rows[e] = np.clip(self.ctrl0 - self.K @ dx, lo, hi)
+
+
+__all__ = ["ZeroController", "PositionTargetDemo", "RandomCtrlController", "LinearFeedbackController", "philox_uniform"]

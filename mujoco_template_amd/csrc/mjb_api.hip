@@ -78,6 +78,9 @@ struct mjbData {
   DevDebug<float> dbgf;
   DevDebug<double> dbgd;
   std::map<std::string, ArrayInfo> dbg_arrays;
+  // device-side feedback controller gains (float and double copies): K [nu, 2nv], u0 [nu], q0 [nq], v0 [nv]
+  float* fbf[4] = {nullptr, nullptr, nullptr, nullptr};
+  double* fbd[4] = {nullptr, nullptr, nullptr, nullptr};
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   int* fd_valid = nullptr;
@@ -393,12 +396,37 @@ int mjb_rollout(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned st
                 const mjbObsSpec* spec, void* obs_out_dev, int obs_every) {
   if (!d) return fail(MJB_ERR_ARG, "data is NULL");
   if (nstep < 1) return fail(MJB_ERR_ARG, "nstep must be >= 1");
-  if (ctrl_mode < 0 || ctrl_mode > 2) return fail(MJB_ERR_ARG, "bad ctrl_mode");
+  if (ctrl_mode < 0 || ctrl_mode > 3) return fail(MJB_ERR_ARG, "bad ctrl_mode");
+  if (ctrl_mode == 3 && !d->fbd[0]) return fail(MJB_ERR_ARG, "MJB_CTRL_FEEDBACK needs mjb_set_feedback() first");
   HIPCHK(hipSetDevice(d->device));
   StepArgs a = make_args(d, nstep, ctrl_mode, seed, step0, ctrl_scale, 0);
+  if (ctrl_mode == 3) {
+    if (d->dtype == MJB_F32) { a.fb_K = d->fbf[0]; a.fb_u0 = d->fbf[1]; a.fb_q0 = d->fbf[2]; a.fb_v0 = d->fbf[3]; }
+    else { a.fb_K = d->fbd[0]; a.fb_u0 = d->fbd[1]; a.fb_q0 = d->fbd[2]; a.fb_v0 = d->fbd[3]; }
+  }
   ObsSpecDev obs; std::memset(&obs, 0, sizeof(obs));
   if (spec && obs_out_dev && obs_every > 0) { obs = spec->dev; a.obs_every = obs_every; }
   return launch(d, a, obs, obs_out_dev, false);
+}
+
+int mjb_set_feedback(mjbData* d, const double* K, const double* u0, const double* q0, const double* v0) {
+  if (!d || !K || !u0 || !q0) return fail(MJB_ERR_ARG, "NULL argument");
+  const HostModel& h = d->model->h;
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  const size_t n[4] = {(size_t)h.nu * 2 * h.nv, (size_t)h.nu, (size_t)h.nq, (size_t)h.nv};
+  const double* src[4] = {K, u0, q0, v0};
+  for (int k = 0; k < 4; k++) {
+    if (!d->fbd[k] && (dev_alloc(d, &d->fbd[k], n[k]) || dev_alloc(d, &d->fbf[k], n[k]))) return fail(MJB_ERR_DEVICE, "device allocation of feedback gains failed");
+    std::vector<double> vd(n[k], 0.0);
+    if (src[k]) vd.assign(src[k], src[k] + n[k]);
+    std::vector<float> vf(vd.begin(), vd.end());
+    if (n[k]) {
+      HIPCHK(hipMemcpy(d->fbd[k], vd.data(), n[k] * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d->fbf[k], vf.data(), n[k] * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  return MJB_OK;
 }
 
 int mjb_obs_spec_create(mjbData* d, int flags, int nsite, const int* site_ids, int nbody, const int* body_ids,

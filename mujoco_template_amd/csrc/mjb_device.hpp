@@ -1500,6 +1500,50 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   gsync<G>();
 }
 
+// A12 sensors of the last forward pass: jointpos, gyro, framequat, accelerometer (lanes over sensors)
+template <typename T, typename TS, int G> MJB_DEV void sensors(const Ctx<T>& c, TS* dst) {
+  ModelRef<T> m = *c.mp; LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
+  for (int s = lane; s < m.nsensor; s += G) {
+    TS* out = dst + m.sensor_adr[s];
+    int id = m.sensor_objid[s], st = m.sensor_type[s];
+    if (st == SENS_JOINTPOS) { out[0] = (TS)w[L.qpos + m.jnt_qposadr[id]]; continue; }
+    int b = m.site_bodyid[id];
+    T R[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = w[L.site_xmat + 9 * id + k];
+    if (st == SENS_GYRO) {
+      T wv[3] = {w[L.cvel + 6 * b], w[L.cvel + 6 * b + 1], w[L.cvel + 6 * b + 2]}, o3[3];
+      mulmatTvec3(o3, R, wv);
+      out[0] = (TS)o3[0]; out[1] = (TS)o3[1]; out[2] = (TS)o3[2];
+    } else if (st == SENS_FRAMEQUAT) {
+      T bq[4] = {w[L.xquat + 4 * b], w[L.xquat + 4 * b + 1], w[L.xquat + 4 * b + 2], w[L.xquat + 4 * b + 3]};
+      T sq[4] = {m.site_quat[4 * id], m.site_quat[4 * id + 1], m.site_quat[4 * id + 2], m.site_quat[4 * id + 3]}, q[4];
+      quat_mul(q, bq, sq);
+      quat_normalize(q);
+      out[0] = (TS)q[0]; out[1] = (TS)q[1]; out[2] = (TS)q[2]; out[3] = (TS)q[3];
+    } else if (st == SENS_ACCEL) {
+      // full com-based acceleration of the body = bias part kept from the velocity stage + sum of cdof * qacc over its dofs
+      T cv[6], ca[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { cv[k] = w[L.cvel + 6 * b + k]; ca[k] = w[L.cacc + 6 * b + k]; }
+      for (int i = 0; i < m.nv; i++) {
+        if (!((m.body_dofmask[b] >> i) & 1ull)) continue;
+        T qa = w[L.qacc + i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) ca[k] += w[L.cdof + 6 * i + k] * qa;
+      }
+      int r = m.body_rootid[b];
+      T dif[3] = {w[L.site_xpos + 3 * id] - w[L.subtree_com + 3 * r], w[L.site_xpos + 3 * id + 1] - w[L.subtree_com + 3 * r + 1], w[L.site_xpos + 3 * id + 2] - w[L.subtree_com + 3 * r + 2]};
+      T t[3], vlin[3], alin[3], wl[3], vl[3], al[3], cr[3];
+      cross3(t, cv, dif); vlin[0] = cv[3] + t[0]; vlin[1] = cv[4] + t[1]; vlin[2] = cv[5] + t[2];
+      cross3(t, ca, dif); alin[0] = ca[3] + t[0]; alin[1] = ca[4] + t[1]; alin[2] = ca[5] + t[2];
+      mulmatTvec3(wl, R, cv); mulmatTvec3(vl, R, vlin); mulmatTvec3(al, R, alin);
+      cross3(cr, wl, vl);
+      out[0] = (TS)(al[0] + cr[0]); out[1] = (TS)(al[1] + cr[1]); out[2] = (TS)(al[2] + cr[2]);
+    } else { out[0] = 0; }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // mj_forward for one environment (state in LDS)
 // ---------------------------------------------------------------------------
@@ -1513,6 +1557,7 @@ template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
   vel_bias_passive<T, G>(c); MJB_STAMP(c, PH_VEL);
   actuation_acceleration<T, G>(c); MJB_STAMP(c, PH_ACT);
   solve_constraints<T, G>(c); MJB_STAMP(c, PH_SOLVE);
+  if (c.mp->nsensor > 0) { sensors<T, T, G>(c, c.w + c.lp->sens); gsync<G>(); }   // like mj_forward: sensors see the pre-integration state
 }
 
 // A16 position integration for the joints of one environment (lanes over joints)
@@ -1599,6 +1644,33 @@ template <typename T, int G> MJB_DEV void random_ctrl(ModelRef<T> m, T* ctrl, un
   }
 }
 
+// Linear state-feedback controller evaluated on the device (the LQR law of the reference's examples,
+// examples/humanoid/controllers/lqr.py:147-170): ctrl = clip(u0 - K dx), dx = [q (-) q0 ; qvel - v0] in tangent space.
+template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, const StepArgs& a) {
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nu = m.nu;
+  auto K = (const T MJB_CONST*)a.fb_K; auto u0 = (const T MJB_CONST*)a.fb_u0;
+  auto q0 = (const T MJB_CONST*)a.fb_q0; auto v0 = (const T MJB_CONST*)a.fb_v0;
+  T *dx = w + L.grad, *qpos = w + L.qpos, *qvel = w + L.qvel, *ctrl = w + L.ctrl;   // grad|search are contiguous: 2 nv of scratch
+  for (int j = lane; j < m.njnt; j += G) {
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    if (m.jnt_type[j] == JNT_FREE) {
+      dx[da] = qpos[qa] - q0[qa]; dx[da + 1] = qpos[qa + 1] - q0[qa + 1]; dx[da + 2] = qpos[qa + 2] - q0[qa + 2];
+      T qa4[4] = {q0[qa + 3], q0[qa + 4], q0[qa + 5], q0[qa + 6]}, qb4[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]}, r[3];
+      quat_sub(r, qa4, qb4);
+      dx[da + 3] = r[0]; dx[da + 4] = r[1]; dx[da + 5] = r[2];
+    } else dx[da] = qpos[qa] - q0[qa];
+  }
+  for (int i = lane; i < nv; i += G) dx[nv + i] = qvel[i] - v0[i];
+  gsync<G>();
+  for (int act = lane; act < nu; act += G) {
+    T u = u0[act];
+    for (int k = 0; k < 2 * nv; k++) u -= K[act * 2 * nv + k] * dx[k];
+    if (m.actuator_ctrllimited[act]) u = t_min(t_max(u, m.actuator_ctrlrange[2 * act]), m.actuator_ctrlrange[2 * act + 1]);
+    ctrl[act] = u;
+  }
+  gsync<G>();
+}
+
 // A13 bad-state guard
 template <typename T, int G> MJB_DEV bool group_bad(const T* x, int n, int lane) {
   int bad = 0;
@@ -1626,7 +1698,7 @@ template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c
   o += 3 * s.ngeom;
   if (s.flags & 1) { for (int i = lane; i < m.nq; i += G) out[o + i] = (TS)w[L.qpos + i]; o += m.nq; }
   if (s.flags & 2) { for (int i = lane; i < m.nv; i += G) out[o + i] = (TS)w[L.qvel + i]; o += m.nv; }
-  if (s.flags & 8) { for (int i = lane; i < m.nsensordata; i += G) out[o + i] = (TS)0; o += m.nsensordata; }
+  if (s.flags & 8) { for (int i = lane; i < m.nsensordata; i += G) out[o + i] = (TS)w[L.sens + i]; o += m.nsensordata; }
   for (int i = lane; i < 3 * s.nsite; i += G) out[o + i] = (TS)w[L.site_xpos + 3 * s.site_ids[i / 3] + i % 3];
   o += 3 * s.nsite;
   for (int i = lane; i < 3 * s.nsubtree; i += G) out[o + i] = (TS)w[L.subtree_com + 3 * s.subtree_ids[i / 3] + i % 3];
@@ -1665,7 +1737,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
       if (a.ctrl_mode == CTRL_RANDOM) {
         random_ctrl<T, G>(m, w + L.ctrl, a.seed, a.env0 + (unsigned)env, a.step0 + (unsigned)s, (T)a.ctrl_scale, lane);
         gsync<G>();
-      }
+      } else if (a.ctrl_mode == CTRL_FEEDBACK) feedback_ctrl<T, G>(c, a);
     }
     bool retried = false;
     for (int st = 0; st < nstage; st++) {
@@ -1713,27 +1785,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     for (int i = lane; i < 4 * m.nbody; i += G) d.xquat[(size_t)env * 4 * m.nbody + i] = (TS)w[L.xquat + i];
     for (int i = lane; i < 3 * m.nsite; i += G) d.site_xpos[(size_t)env * 3 * m.nsite + i] = (TS)w[L.site_xpos + i];
     for (int i = lane; i < 3 * m.ngeom; i += G) d.geom_xpos[(size_t)env * 3 * m.ngeom + i] = (TS)w[L.geom_xpos + i];
-    // A12 sensors of the position/velocity stages (accelerometer needs the post-constraint cacc pass: not built yet -> 0)
-    for (int s = lane; s < m.nsensor; s += G) {
-      TS* out = d.sensordata + (size_t)env * m.nsensordata + m.sensor_adr[s];
-      int id = m.sensor_objid[s], st = m.sensor_type[s];
-      if (st == SENS_JOINTPOS) out[0] = (TS)w[L.qpos + m.jnt_qposadr[id]];
-      else if (st == SENS_GYRO) {
-        int b = m.site_bodyid[id];
-        T R[9], wv[3] = {w[L.cvel + 6 * b], w[L.cvel + 6 * b + 1], w[L.cvel + 6 * b + 2]}, o3[3];
-#pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = w[L.site_xmat + 9 * id + k];
-        mulmatTvec3(o3, R, wv);
-        out[0] = (TS)o3[0]; out[1] = (TS)o3[1]; out[2] = (TS)o3[2];
-      } else if (st == SENS_FRAMEQUAT) {
-        int b = m.site_bodyid[id];
-        T bq[4] = {w[L.xquat + 4 * b], w[L.xquat + 4 * b + 1], w[L.xquat + 4 * b + 2], w[L.xquat + 4 * b + 3]};
-        T sq[4] = {m.site_quat[4 * id], m.site_quat[4 * id + 1], m.site_quat[4 * id + 2], m.site_quat[4 * id + 3]}, q[4];
-        quat_mul(q, bq, sq);
-        quat_normalize(q);
-        out[0] = (TS)q[0]; out[1] = (TS)q[1]; out[2] = (TS)q[2]; out[3] = (TS)q[3];
-      } else { out[0] = 0; out[1] = 0; out[2] = 0; }
-    }
+    for (int i = lane; i < m.nsensordata; i += G) d.sensordata[(size_t)env * m.nsensordata + i] = (TS)w[L.sens + i];
   }
   // optional per-phase dumps (forward mode, parity tests)
   if (dbg.qM) for (int i = lane; i < nv * nv; i += G) dbg.qM[(size_t)env * nv * nv + i] = (TS)w[L.M + i];

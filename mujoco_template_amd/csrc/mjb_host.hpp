@@ -43,7 +43,7 @@ struct Table {
 // Host copy of everything (float64 / int32), plus derived tables.
 struct HostModel {
   int nq = 0, nv = 0, nu = 0, nbody = 0, njnt = 0, ngeom = 0, nsite = 0, ntendon = 0, nwrap = 0, nsensor = 0, nsensordata = 0, nkey = 0, npair = 0;
-  int integrator = 0, disableactuator = 0, iterations = 100, nlevel = 0, has_damping = 0, has_fluid = 0, nvp = 1, nvshift = 0;
+  int integrator = 0, disableactuator = 0, iterations = 100, nlevel = 0, has_damping = 0, has_fluid = 0, has_accel = 0, nvp = 1, nvshift = 0;
   int ncon_alloc = 0, nefc_alloc = 0;
   double timestep = 0, gravity[3] = {0, 0, 0}, density = 0, viscosity = 0, tolerance = 1e-8, meaninertia = 1;
   std::vector<std::pair<std::string, std::vector<double>>> fd;
@@ -148,6 +148,8 @@ struct HostModel {
     has_damping = 0;
     for (double v : D("dof_damping")) if (v > 0) has_damping = 1;
     has_fluid = (density > 0 || viscosity > 0) ? 1 : 0;
+    has_accel = 0;
+    for (int t : I("sensor_type")) if (t == SENS_ACCEL) has_accel = 1;
     nvp = 1; nvshift = 0;
     while (nvp < nv) { nvp <<= 1; nvshift++; }
     const auto& g1 = I("pair_geom1"); const auto& g2 = I("pair_geom2"); const auto& gt = I("geom_type");
@@ -169,7 +171,7 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   m.nq = h.nq; m.nv = h.nv; m.nu = h.nu; m.nbody = h.nbody; m.njnt = h.njnt; m.ngeom = h.ngeom; m.nsite = h.nsite;
   m.ntendon = h.ntendon; m.nwrap = h.nwrap; m.nsensor = h.nsensor; m.nsensordata = h.nsensordata; m.nkey = h.nkey; m.npair = h.npair;
   m.nlevel = h.nlevel; m.integrator = h.integrator; m.disableactuator = h.disableactuator; m.iterations = h.iterations;
-  m.has_damping = h.has_damping; m.has_fluid = h.has_fluid; m.nvp = h.nvp; m.nvshift = h.nvshift;
+  m.has_damping = h.has_damping; m.has_fluid = h.has_fluid; m.has_accel = h.has_accel; m.nvp = h.nvp; m.nvshift = h.nvshift;
   m.ncon_max = ncon_max; m.nefc_max = nefc_max; m.nsiteact = (int)h.siteact.size(); m.nmpair = (int)h.mpair.size();
   m.timestep = (T)h.timestep; m.gravity[0] = (T)h.gravity[0]; m.gravity[1] = (T)h.gravity[1]; m.gravity[2] = (T)h.gravity[2];
   m.density = (T)h.density; m.viscosity = (T)h.viscosity; m.meaninertia = (T)h.meaninertia;
@@ -223,10 +225,11 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   L.xpos = A(3 * nb); L.xquat = A(4 * nb); L.xipos = A(3 * nb); L.ximat = A(9 * nb);
   L.geom_xpos = A(3 * ng); L.site_xpos = A(3 * ns); L.site_xmat = A(9 * ns);
   L.subtree_com = A(3 * nb); L.cinert = A(10 * nb); L.cdof = A(6 * nv); L.cvel = A(6 * nb); L.bfrc = A(h.has_fluid ? 6 * nb : 0);
-  L.M = A(nv * nv); L.W = A(nv * (nv + 1) / 2); L.ten_length = A(nt); L.ten_J = A(nt * nv); L.act_force = A(nu);
+  L.M = A(nv * nv); L.W = A(nv * (nv + 1) / 2); L.ten_length = A(nt); L.ten_J = A(nt * nv); L.act_force = A(nu); L.sens = A(h.nsensordata);
   L.con = A(ncon_max * CON_STRIDE);
   L.efc_J = A(nefc_max * nv); L.efc_pos = A(nefc_max); L.efc_D = A(nefc_max); L.efc_aref = A(nefc_max);
   L.tmp = A(nv);
+  if (h.has_accel) L.cacc = A(6 * nb);          // accelerometers read the bias acceleration after the solve: keep it out of the overlay
   // One overlay region for temporaries with disjoint lifetimes (forward() order: kinematics, com_pos, collision,
   // crb, make_constraint, velocity stage, actuation, solver):
   //   g1 (kinematics .. collision):  xmat, xanchor, xaxis, geom_xmat
@@ -239,7 +242,7 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   if (o > rend) rend = o; o = r0;
   L.crb = A(10 * nb); L.dofbuf = A(6 * nv);
   if (o > rend) rend = o; o = r0;
-  L.cdof_dot = A(6 * nv); L.cacc = A(6 * nb); L.cfrc = A(6 * nb);
+  L.cdof_dot = A(6 * nv); if (!h.has_accel) L.cacc = A(6 * nb); L.cfrc = A(6 * nb);
   if (o > rend) rend = o; o = r0;
   L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.cholcol = A(nv + 1);
   L.efc_jar = A(nefc_max); L.efc_jv = A(nefc_max); L.efc_force = A(nefc_max); L.efc_KBI = A(nefc_max);

@@ -24,7 +24,7 @@ enum { TRN_JOINT = 0, TRN_SITE = 4 };
 enum { INT_EULER = 0, INT_RK4 = 1 };
 enum { SENS_JOINTPOS = 0, SENS_GYRO, SENS_ACCEL, SENS_FRAMEQUAT };
 enum { EFC_LIMIT_JOINT = 0, EFC_LIMIT_TENDON = 1, EFC_CONTACT_FRICTIONLESS = 2, EFC_CONTACT_PYRAMIDAL = 3 };
-enum { CTRL_KEEP = 0, CTRL_ZERO = 1, CTRL_RANDOM = 2 };
+enum { CTRL_KEEP = 0, CTRL_ZERO = 1, CTRL_RANDOM = 2, CTRL_FEEDBACK = 3 };
 
 // counters written per environment (int[8])
 enum { CNT_NCON = 0, CNT_NEFC, CNT_NITER, CNT_CON_DROPPED, CNT_EFC_DROPPED, CNT_BADQPOS, CNT_BADQVEL, CNT_BADQACC, CNT_N };
@@ -35,7 +35,7 @@ struct DevModel {
   typedef const int MJB_CONST* IP;                   // int table
   typedef const unsigned long long MJB_CONST* UP;    // 64-bit dof mask table
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nsensor, nsensordata, nkey, npair;
-  int nlevel, integrator, disableactuator, iterations, has_damping, has_fluid, nvp, nvshift;
+  int nlevel, integrator, disableactuator, iterations, has_damping, has_fluid, has_accel, nvp, nvshift;
   int ncon_max, nefc_max, nsiteact, nmpair;
   T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
   // kinematic tree
@@ -77,7 +77,7 @@ struct Lay {
   int qfrc_bias, qfrc_passive, qfrc_actuator, qfrc_smooth, qfrc_constraint;
   int xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, geom_xpos, geom_xmat, site_xpos, site_xmat;
   int subtree_com, cinert, crb, cdof, cdof_dot, cvel, cacc, cfrc, dofbuf, bfrc;
-  int M, W, ten_length, ten_J, act_force;
+  int M, W, ten_length, ten_J, act_force, sens;   // sens: sensordata of the last forward pass
   int con;            // contacts: ncon_max * CON_STRIDE
   int efc_J, efc_pos, efc_D, efc_aref, efc_jar, efc_jv, efc_force, efc_KBI;
   int Ma, grad, search, Mv, tmp, cholcol;   // tmp = 1/diag(L); cholcol = scaled pivot column (nv+1)
@@ -126,6 +126,8 @@ struct StepArgs {
   int mode;              // 0 = step, 1 = forward only
   int write_kin;         // write xpos/xipos/site_xpos/geom_xpos/subtree_com/sensordata of the last forward pass
   int obs_every;         // >0: write flat obs every k steps into obs_out[(step/k), env, dim]
+  // CTRL_FEEDBACK: ctrl = clip(u0 - K [differentiatePos(q0, qpos); qvel - v0]) with K [nu, 2nv] row-major (dtype of the arithmetic)
+  const void *fb_K, *fb_u0, *fb_q0, *fb_v0;
 };
 
 }  // namespace mjb

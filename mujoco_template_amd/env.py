@@ -20,7 +20,7 @@ from typing import Any
 
 import numpy as np
 
-from ._capi import CTRL_KEEP, CTRL_RANDOM, CTRL_ZERO
+from ._capi import CTRL_FEEDBACK, CTRL_KEEP, CTRL_RANDOM, CTRL_ZERO
 from ._typing import InfoDict, JacobiansDict, Observation
 from .compat import check_controller_compat
 from .control import Controller
@@ -133,7 +133,7 @@ class Env:
         caps = self.controller.capabilities
         if mode is None or caps.needs_linearization or tuple(caps.needs_jacobians) or self.control_decimation != 1:
             return None
-        return {"zero": CTRL_ZERO, "random": CTRL_RANDOM}.get(mode)
+        return {"zero": CTRL_ZERO, "random": CTRL_RANDOM, "feedback": CTRL_FEEDBACK}.get(mode)
 
     def can_fuse(self) -> bool:
         """True when nothing on the host has to observe individual steps (controller on device, no reward/done/info hooks)."""
@@ -155,6 +155,9 @@ class Env:
         data.push_host_edits()
         seed = int(getattr(self.controller, "seed", 0))
         scale = float(getattr(self.controller, "scale", 1.0))
+        if mode == CTRL_FEEDBACK:
+            ctl = self.controller
+            sim.set_feedback(ctl.K, ctl.ctrl0, ctl.qpos_goal, ctl.qvel_goal)
         spec = ptr = None
         if obs_every > 0:
             import torch

@@ -1174,8 +1174,20 @@ static void solve_constraints(const mjoModel* m, mjoData* d) {
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 
-/* A12 sensors (position / velocity kinds only; accelerometer not restated yet -> 0) */
+/* A12 sensors: jointpos, gyro, framequat, accelerometer (needs cacc with qacc: mj_rnePostConstraint) */
 static void sensors(const mjoModel* m, mjoData* d) {
+  int need_acc = 0;
+  for (int s = 0; s < m->nsensor; s++) if (m->sensor_type[s] == SENS_ACCEL) need_acc = 1;
+  if (need_acc) {   /* cacc <- [0; -g] + sum over ancestors of (cdof_dot qvel + cdof qacc) */
+    memset(d->cacc, 0, sizeof(double) * 6);
+    d->cacc[3] = -m->gravity[0]; d->cacc[4] = -m->gravity[1]; d->cacc[5] = -m->gravity[2];
+    for (int b = 1; b < m->nbody; b++) {
+      double* ca = d->cacc + 6 * b;
+      memcpy(ca, d->cacc + 6 * m->body_parentid[b], 48);
+      for (int j = m->body_dofadr[b]; j < m->body_dofadr[b] + m->body_dofnum[b]; j++)
+        for (int c = 0; c < 6; c++) ca[c] += d->cdof_dot[6 * j + c] * d->qvel[j] + d->cdof[6 * j + c] * d->qacc[j];
+    }
+  }
   for (int s = 0; s < m->nsensor; s++) {
     double* out = d->sensordata + m->sensor_adr[s];
     int id = m->sensor_objid[s];
@@ -1183,7 +1195,19 @@ static void sensors(const mjoModel* m, mjoData* d) {
       case SENS_JOINTPOS: out[0] = d->qpos[m->jnt_qposadr[id]]; break;
       case SENS_GYRO: mulmatTvec3(out, d->site_xmat + 9 * id, d->cvel + 6 * m->site_bodyid[id]); break;
       case SENS_FRAMEQUAT: { double q[4]; quat_mul(q, d->xquat + 4 * m->site_bodyid[id], m->site_quat + 4 * id); quat_normalize(q); memcpy(out, q, 32); } break;
-      default: out[0] = out[1] = out[2] = 0;
+      case SENS_ACCEL: {   /* mj_objectAcceleration(site, local): transport com-based cvel / cacc to the site, rotate, add w x v */
+        int b = m->site_bodyid[id];
+        const double *R = d->site_xmat + 9 * id, *cv = d->cvel + 6 * b, *ca = d->cacc + 6 * b;
+        const double* rc = d->subtree_com + 3 * m->body_rootid[b];
+        double dif[3] = {d->site_xpos[3 * id] - rc[0], d->site_xpos[3 * id + 1] - rc[1], d->site_xpos[3 * id + 2] - rc[2]};
+        double t[3], vlin[3], alin[3], wl[3], vl[3], al[3], cr[3];
+        cross3(t, cv, dif); for (int k = 0; k < 3; k++) vlin[k] = cv[3 + k] + t[k];
+        cross3(t, ca, dif); for (int k = 0; k < 3; k++) alin[k] = ca[3 + k] + t[k];
+        mulmatTvec3(wl, R, cv); mulmatTvec3(vl, R, vlin); mulmatTvec3(al, R, alin);
+        cross3(cr, wl, vl);
+        out[0] = al[0] + cr[0]; out[1] = al[1] + cr[1]; out[2] = al[2] + cr[2];
+      } break;
+      default: out[0] = 0;
     }
   }
 }

@@ -297,3 +297,34 @@ def test_batched_env_shapes_and_linearization():
     assert r.info["A"].shape == (512, 4, 4) and r.info["B"].shape == (512, 4, 1)
     assert r.obs["qpos"].shape == (512, 2)
     assert np.allclose(r.info["A"][0], r.info["A"][511])          # identical replicas -> identical linearisation
+
+
+def test_linear_feedback_controller_fused_equals_host_loop():
+    """LinearFeedbackController: the fused device evaluation and the per-step host __call__ drive the same trajectory."""
+    rng = np.random.default_rng(2)
+    probe = mt.Env.from_xml_path(MODELS["drone2"], keyframe="hover", batch=2)
+    nu, nv = probe.model.nu, probe.model.nv
+    K = rng.normal(size=(nu, 2 * nv)) * 0.3
+    q_goal, u_goal = np.array(probe.data.qpos[0]), np.array(probe.data.ctrl[0])
+
+    class HostOnly:                                    # same law, but without device_ctrl_mode: forces the reference-style loop
+        def __init__(self, inner):
+            self.inner, self.capabilities = inner, inner.capabilities
+        def prepare(self, model, data):
+            self.inner.prepare(model, data)
+        def __call__(self, model, data, t):
+            self.inner(model, data, t)
+
+    def make(ctl):
+        env = mt.Env.from_xml_path(MODELS["drone2"], controller=ctl, keyframe="hover", batch=8, dtype="float64")
+        env.data.qpos[:, 2] += np.linspace(0.0, 0.07, 8)     # different height offsets -> different feedback
+        return env
+
+    a = make(mt.LinearFeedbackController(K=K, ctrl0=u_goal, qpos_goal=q_goal))
+    b = make(HostOnly(mt.LinearFeedbackController(K=K, ctrl0=u_goal, qpos_goal=q_goal)))
+    assert a.can_fuse() and not b.can_fuse()
+    a.rollout(40)
+    for _ in range(40):
+        b.step(return_obs=False)
+    assert np.abs(np.array(a.data.qpos) - np.array(b.data.qpos)).max() < 1e-9
+    assert np.abs(np.array(a.data.ctrl) - np.array(b.data.ctrl)).max() < 1e-9

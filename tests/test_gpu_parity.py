@@ -216,6 +216,23 @@ def test_lanes_per_env_variants_agree(world, lanes):
     assert sim.counters()["ncon"][0] == od.counters()["ncon"] > 0
 
 
+def test_sensors_match_oracle(world):
+    cm, om, dm = world("drone2")
+    B = 8
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    q, v, u = random_states(cm, ods[0], B, 21, qs=0.2, vs=0.5)
+    q[:, 2] += 1.0
+    u = (u + 1) * 3.0
+    for dtype, tol in (("float64", 1e-11), ("float32", 2e-4)):
+        sim = BatchSim(dm, B, dtype=dtype)
+        sim.set("qpos", q); sim.set("qvel", v); sim.set("ctrl", u)
+        sim.step(1)
+        for e, od in enumerate(ods):
+            od.reset(); od.qpos[:] = q[e]; od.qvel[:] = v[e]; od.ctrl[:] = u[e]; od.step()
+        ref = np.stack([od.sensordata for od in ods])
+        assert np.abs(sim.get("sensordata") - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
 def test_caps_drop_the_same_rows_as_the_oracle(world):
     cm, om0, dm = world("humanoid")
     om = mjo.OracleModel(cm)
@@ -325,3 +342,43 @@ def test_full_size_humanoid_properties(world):
     sim.rollout(60, CTRL_RANDOM, seed=0)
     qo, _ = mjo.rollout_batch(om, 8, 60, seed=0, nthreads=4)
     assert np.abs(sim.get("qpos") - qo).max() < 5e-4
+
+
+def test_device_feedback_controller_matches_host_law(world):
+    """CTRL_FEEDBACK (the reference examples' LQR law u = clip(u0 - K [q (-) q0; v - v0])) evaluated in the fused kernel
+    vs the same law evaluated with numpy around the oracle, float64: rounding-level agreement; fp32: one-step level."""
+    import mujoco_template_amd as mt
+    from mujoco_template_amd import mj
+
+    for name, key in (("drone2", 0), ("cartpole", None)):
+        cm, om, dm = world(name)
+        rng = np.random.default_rng(5)
+        K = rng.normal(size=(cm.nu, 2 * cm.nv)) * 0.5
+        q0 = np.array(cm.key_qpos[0] if key is not None else cm.qpos0)
+        u0 = np.array(cm.key_ctrl[0] if key is not None else np.zeros(cm.nu))
+        v0 = rng.normal(size=cm.nv) * 0.01
+        B, T = 4, 60
+        ods = [mjo.OracleData(om) for _ in range(B)]
+        q, v, _ = random_states(cm, ods[0], B, 6, qs=0.02, vs=0.05)
+        q = np.stack([ods[0].integrate_pos(q0, rng.normal(size=cm.nv) * 0.02, 1.0) for _ in range(B)])
+        model = mj.MjModel(cm)
+        lo = np.where(cm.actuator_ctrllimited, cm.actuator_ctrlrange[:, 0], -np.inf)
+        hi = np.where(cm.actuator_ctrllimited, cm.actuator_ctrlrange[:, 1], np.inf)
+        for e, od in enumerate(ods):
+            od.qpos[:] = q[e]; od.qvel[:] = v[e]
+            for _ in range(T):
+                dq = np.zeros(cm.nv)
+                mj.mj_differentiatePos(model, dq, 1.0, q0, np.array(od.qpos))
+                od.ctrl[:] = np.clip(u0 - K @ np.concatenate([dq, od.qvel - v0]), lo, hi)
+                od.step()
+        ref = np.stack([od.qpos for od in ods])
+        for dtype, tol in (("float64", 1e-9), ("float32", 5e-4)):
+            sim = BatchSim(dm, B, dtype=dtype)
+            sim.set("qpos", q); sim.set("qvel", v)
+            sim.set_feedback(K, u0, q0, v0)
+            from mujoco_template_amd._capi import CTRL_FEEDBACK
+            sim.rollout(T, CTRL_FEEDBACK)
+            assert np.abs(sim.get("qpos") - ref).max() <= tol, (name, dtype)
+            assert np.abs(sim.get("ctrl") - np.stack([od.ctrl for od in ods])).max() <= (1e-8 if dtype == "float64" else 5e-3)
+    with pytest.raises(mt.ConfigError):
+        BatchSim(world("cartpole")[2], 2).rollout(1, 3)          # feedback mode without gains

@@ -89,3 +89,18 @@ def test_bad_state_resets_like_mj_checkpos(compiled):
     od.step(); e.step()
     assert od.counters()["warn_badqpos"] == 1 and e.counters[5] == 1
     assert np.isfinite(e.qpos).all() and np.abs(e.qpos - od.qpos).max() < 1e-12
+
+
+def test_drone_sensors_match_oracle(compiled):
+    """gyro / accelerometer / framequat (x2.xml:83-87): emulated kernel vs oracle, in flight and after a step."""
+    cm, od, e = _pair(compiled, "drone2", 16)
+    rng = np.random.default_rng(4)
+    q = od.integrate_pos(cm.qpos0, rng.normal(size=6) * 0.3, 1.0); q[2] += 1.0
+    v = rng.normal(size=6)
+    u = np.array([4.0, 3.0, 5.0, 2.0])
+    od.qpos[:] = q; od.qvel[:] = v; od.ctrl[:] = u
+    e.qpos[:] = q; e.qvel[:] = v; e.ctrl[:4] = u
+    od.forward(); e.forward()
+    assert np.abs(e.sensordata[:10] - od.sensordata).max() < 1e-11
+    od.step(); e.step()                        # sensordata keeps the values of the forward pass inside the step
+    assert np.abs(e.sensordata[:10] - od.sensordata).max() < 1e-11

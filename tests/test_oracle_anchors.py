@@ -284,3 +284,14 @@ def test_solver_reaches_kkt_on_humanoid(oracle):
     assert d.qfrc_constraint == pytest.approx(J.T @ f, abs=1e-9)
     jar = J @ d.qacc - d.efc_aref
     assert f == pytest.approx(np.where(jar < 0, -d.efc_D * jar, 0.0), abs=1e-9)
+
+
+def test_accelerometer_gyro_anchors(oracle):
+    """Hovering drone: accelerometer reads +g along body z, gyro 0, framequat identity; in free fall it reads 0."""
+    m, d = oracle("drone2")
+    d.reset_keyframe(0); d.forward()
+    assert d.sensordata == pytest.approx([0, 0, 0, 0, 0, G, 1, 0, 0, 0], abs=1e-12)
+    d.reset(); d.qpos[2] += 3.0; d.forward()
+    assert np.abs(d.sensordata[3:6]).max() < 1e-12
+    d.qvel[3:6] = [0.0, 0.0, 2.0]; d.forward()             # spinning about body z: gyro reads the spin, imu on the axis feels no centripetal term
+    assert d.sensordata[:3] == pytest.approx([0, 0, 2.0], abs=1e-12)
