@@ -33,7 +33,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--global-batch", type=int, default=4096)
     ap.add_argument("--chunk", type=int, default=100, help="simulation steps fused per kernel launch")
     ap.add_argument("--weak", action="store_true", help="fixed per-GPU batch (= --global-batch per rank) instead of sharding it")
