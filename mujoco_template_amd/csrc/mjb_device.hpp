@@ -520,6 +520,89 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
 }
 #endif
 
+// ---------------------------------------------------------------------------
+// MFMA Cholesky (fp32, G == 64, n <= 32): the symmetric 32x32 matrix lives in the accumulator layout of
+// v_mfma_f32_32x32x2_f32 (lane l: column l%32, 16 rows 8q + 4(l/32) + t).  By symmetry "row j across lanes" IS
+// column j of the factor, so a panel of two columns costs a handful of VALU ops and the rank-2 trailing update
+// of the whole matrix is ONE MFMA (exact fp32 FMAs).  The Hessian M + J^T D J is assembled the same way:
+// one MFMA per pair of constraint rows.  Forward substitution is fused; L goes to LDS (packed) for the
+// backward substitution and for reuse when the active set does not change.
+// ---------------------------------------------------------------------------
+#ifndef MJB_HOST_EMU
+typedef float mjb_f16v __attribute__((ext_vector_type(16)));
+MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane half, column-aligned, in all 64 lanes
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(half == 0 ? p[0] : p[1]);
+}
+template <typename MRef>
+MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x) {
+  const int h = lane >> 5, c = lane & 31;
+  mjb_f16v acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int row = 8 * (i >> 2) + 4 * h + (i & 3);
+    float v = (row < n && c < n) ? M[row * n + c] : ((row == c) ? 1.0f : 0.0f);
+    if (mode == 2 && row == c && row < n) v += m.timestep * m.dof_damping[row];
+    acc[i] = v;
+  }
+  if (mode == 1) {
+    for (int r0 = 0; r0 < nefc; r0 += 2) {
+      int rr = r0 + h;
+      float d = rr < nefc ? dw[rr] : 0.0f;
+      float d0 = dw[r0], d1 = (r0 + 1 < nefc) ? dw[r0 + 1] : 0.0f;
+      if (d0 == 0.0f && d1 == 0.0f) continue;                 // uniform: both rows inactive
+      float jv_ = (rr < nefc && c < n) ? J[rr * n + c] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(d * jv_, jv_, acc, 0, 0, 0);
+    }
+  }
+  float r = (x && c < n) ? x[c] : 0.0f;                       // RHS replicated in both halves (lane -> row c)
+  float myinv = 1.0f;
+#pragma unroll
+  for (int jb = 0; jb < 16; jb++) {
+    const int j0 = 2 * jb, j1 = j0 + 1, hj = (j0 >> 2) & 1, ij = 4 * (j0 >> 3) + (j0 & 3);
+    // column j0 of L = row j0 of the (symmetric) matrix, one entry per lane
+    float v0 = half_bcast(acc[ij], hj);
+    float p0 = t_max(rdlane_f(v0, j0), Num<float>::minval());
+    float inv0 = t_rsqrt(p0);
+    float L0 = c > j0 ? v0 * inv0 : (c == j0 ? p0 * inv0 : 0.0f);
+    if (c == j0) myinv = inv0;
+    float y0 = rdlane_f(r, j0) * inv0;
+    r = c > j0 ? r - L0 * y0 : (c == j0 ? y0 : r);
+    // column j1: first the rank-1 correction from column j0, then the same
+    float v1 = half_bcast(acc[ij + 1], hj) - rdlane_f(L0, j1) * L0;
+    float p1 = t_max(rdlane_f(v1, j1), Num<float>::minval());
+    float inv1 = t_rsqrt(p1);
+    float L1 = c > j1 ? v1 * inv1 : (c == j1 ? p1 * inv1 : 0.0f);
+    if (c == j1) myinv = inv1;
+    float y1 = rdlane_f(r, j1) * inv1;
+    r = c > j1 ? r - L1 * y1 : (c == j1 ? y1 : r);
+    if (h == 0 && c < n) {
+      if (c >= j0 && j0 < n) W[tri_at(c, j0)] = L0;
+      if (c >= j1 && j1 < n) W[tri_at(c, j1)] = L1;
+    }
+    // rank-2 trailing update of the whole matrix: acc -= [L0 L1] [L0 L1]^T
+    float a = h == 0 ? L0 : L1;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a, a, acc, 0, 0, 0);
+  }
+  if (h == 0 && c < n) dinv[c] = myinv;
+  gsync<64>();
+  if (x) {                                                    // backward substitution L^T x = y from the packed factor in LDS
+    float lrow[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) lrow[j] = (j < n && c < j) ? W[tri_at(j, c)] : 0.0f;
+#pragma unroll
+    for (int j = 31; j >= 0; j--) {
+      float xj = rdlane_f(r, j) * rdlane_f(myinv, j);
+      r = c == j ? xj : r - lrow[j] * xj;
+    }
+    if (h == 0 && c < n) x[c] = r;
+    gsync<64>();
+  }
+}
+template <typename MRef>
+MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*) {}
+#endif
+
 // W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
 // If x != nullptr the system (factor) x = x is solved in the same pass (fused on the register path).
 template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
@@ -527,7 +610,11 @@ template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
   T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *dw = w + L.efc_jv;
   if (G == 64) {
 #ifndef MJB_HOST_EMU
-    if (nv <= 32) { reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x); return; }
+    if (nv <= 32) {
+      if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
+      else reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
+      return;
+    }
 #endif
     tile_factor<T, 8, ModelRef<T>>(m, M, W, w + L.tmp, w + L.cholcol, J, dw, nefc, mode, nv, lane);
     if (x) chol_solve<T, G>(W, w + L.tmp, x, nv, lane);
