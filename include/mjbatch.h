@@ -104,7 +104,7 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
 /* per-phase dumps of the last mjb_forward for parity tests: name in
  * qM qfrc_bias qfrc_passive qfrc_actuator qacc_smooth qfrc_constraint efc_J efc_aref efc_D efc_pos efc_force con cdof cinert cvel (float64 out)
  * and efc_type (int32 out).  Call mjb_debug_forward() first. */
-/* diagnostic build (-DMJB_PROFILE) only: per-phase shader-cycle sums since the last call, host_out[16]; zeros otherwise */
+/* diagnostic build (-DMJB_PROFILE) only: per-phase shader-cycle sums since the last call, host_out[24]; zeros otherwise */
 int mjb_profile_get(mjbData* d, unsigned long long* host_out);
 int mjb_debug_forward(mjbData* d);
 int mjb_debug_get(mjbData* d, const char* name, void* host_out, long capacity_elems);

@@ -277,7 +277,7 @@ class BatchSim:
         return jp, jr
 
     def profile_get(self) -> np.ndarray:
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(24, dtype=np.uint64)
         _check(load_library().mjb_profile_get(self.ptr, out.ctypes.data))
         return out
 

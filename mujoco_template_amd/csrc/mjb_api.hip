@@ -537,7 +537,7 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
   return rc;
 }
 
-int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [16] per-phase cycle sums; zero unless built with -DMJB_PROFILE */) {
+int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [24] per-phase cycle sums; zero unless built with -DMJB_PROFILE */) {
   if (!d || !host_out) return fail(MJB_ERR_ARG, "NULL argument");
   HIPCHK(hipSetDevice(d->device));
   HIPCHK(hipStreamSynchronize(d->stream));

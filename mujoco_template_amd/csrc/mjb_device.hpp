@@ -453,7 +453,7 @@ template <typename T> struct Ctx {
   int lane;
   int ncon, nefc, niter, con_dropped, efc_dropped;
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
-  unsigned long long pacc[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pacc[PH_N] = {};
   unsigned long long pt = 0;
 #endif
   MJB_DEVM Ctx(const DevModel<T> MJB_CONST* m_, const Lay MJB_CONST* L_, T* w_, int* wi_, int lane_) : mp(m_), lp(L_), w(w_), wi(wi_), lane(lane_), ncon(0), nefc(0), niter(0), con_dropped(0), efc_dropped(0) {}
@@ -535,15 +535,18 @@ MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane 
   return __uint_as_float(half == 0 ? p[0] : p[1]);
 }
 template <typename MRef>
-MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x) {
-  const int h = lane >> 5, c = lane & 31;
+MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c = lane & 31, c_ = c;
+  unsigned long long tq0 = pf ? __builtin_amdgcn_s_memtime() : 0;
   mjb_f16v acc;
+  const float ddiag = (mode == 2 && c < n) ? m.timestep * m.dof_damping[c] : 0.0f;     // one load per lane, added on the diagonal
+  const int cm = c < n ? c : 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     int row = 8 * (i >> 2) + 4 * h + (i & 3);
-    float v = (row < n && c < n) ? M[row * n + c] : ((row == c) ? 1.0f : 0.0f);
-    if (mode == 2 && row == c && row < n) v += m.timestep * m.dof_damping[row];
-    acc[i] = v;
+    float mv = M[(row < n ? row : 0) * n + cm];                                         // unconditional LDS read, then select: no exec-mask branches
+    float v = (row < n && c < n) ? mv : ((row == c) ? 1.0f : 0.0f);
+    acc[i] = row == c ? v + ddiag : v;
   }
   if (mode == 1) {
     for (int r0 = 0; r0 < nefc; r0 += 2) {
@@ -557,9 +560,13 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
   }
   float r = (x && c < n) ? x[c] : 0.0f;                       // RHS replicated in both halves (lane -> row c)
   float myinv = 1.0f;
+  unsigned long long tq1 = pf ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
   for (int jb = 0; jb < 16; jb++) {
     const int j0 = 2 * jb, j1 = j0 + 1, hj = (j0 >> 2) & 1, ij = 4 * (j0 >> 3) + (j0 & 3);
+    if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
+    int c = c_;
+    asm volatile("" : "+v"(c));                               // keep the per-column lane compares in the loop (cheaper than spilled masks)
     // column j0 of L = row j0 of the (symmetric) matrix, one entry per lane
     float v0 = half_bcast(acc[ij], hj);
     float p0 = t_max(rdlane_f(v0, j0), Num<float>::minval());
@@ -584,34 +591,60 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     float a = h == 0 ? L0 : L1;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a, a, acc, 0, 0, 0);
   }
+  unsigned long long tq2 = pf ? __builtin_amdgcn_s_memtime() : 0;
   if (h == 0 && c < n) dinv[c] = myinv;
   gsync<64>();
   if (x) {                                                    // backward substitution L^T x = y from the packed factor in LDS
-    float lrow[32];
 #pragma unroll
-    for (int j = 0; j < 32; j++) lrow[j] = (j < n && c < j) ? W[tri_at(j, c)] : 0.0f;
+    for (int blk = 3; blk >= 0; blk--) {                        // 8 rows of L^T at a time: bounded register footprint
+      if (8 * blk >= n) continue;
+      float lrow[8];
 #pragma unroll
-    for (int j = 31; j >= 0; j--) {
-      float xj = rdlane_f(r, j) * rdlane_f(myinv, j);
-      r = c == j ? xj : r - lrow[j] * xj;
+      for (int t = 0; t < 8; t++) {
+        int j = 8 * blk + t, jj = j < n ? j : 0;                // always a valid address; masked by the select below
+        float lv = W[tri_at(jj, c < jj ? c : jj)];
+        lrow[t] = (j < n && c < j) ? lv : 0.0f;
+      }
+#pragma unroll
+      for (int t = 7; t >= 0; t--) {
+        int j = 8 * blk + t;
+        if (j >= n) continue;
+        float xj = rdlane_f(r, j) * rdlane_f(myinv, j);
+        r = c == j ? xj : r - lrow[t] * xj;
+      }
     }
     if (h == 0 && c < n) x[c] = r;
     gsync<64>();
   }
+  if (pf) { unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
 }
 template <typename MRef>
-MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*) {}
+MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 #endif
 
 // W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
 // If x != nullptr the system (factor) x = x is solved in the same pass (fused on the register path).
+template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* x);
 template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+  unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+  factor_W_impl<T, G>(c, mode, x);
+  c.pacc[PH_FAC_ALL] += __builtin_amdgcn_s_memtime() - t0_;   // informational: already inside the enclosing phase's stamp
+#else
+  factor_W_impl<T, G>(c, mode, x);
+#endif
+}
+template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* x) {
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
   T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *dw = w + L.efc_jv;
   if (G == 64) {
 #ifndef MJB_HOST_EMU
     if (nv <= 32) {
+#if defined(MJB_PROFILE)
+      if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x, c.pacc + PH_FAC_LOAD);
+#else
       if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
+#endif
       else reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
       return;
     }
@@ -1488,7 +1521,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
   gsync<G>();
   if (gn < gtol2) return gn;
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
-  c.pacc[13] += 1; if (rebuild) c.pacc[14] += 1;
+  c.pacc[PH_CNT_DIR] += 1; if (rebuild) c.pacc[PH_CNT_FACT] += 1;
 #endif
   if (rebuild) factor_W<T, G>(c, 1, search);
   else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
@@ -1540,7 +1573,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     }
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
     gsync<G>();
-    MJB_STAMP(c, 15);
+    MJB_STAMP(c, PH_SOL_MV);
     // exact line search on the convex piecewise-quadratic: safeguarded Newton on the derivative
     T alpha = 0, lo = 0, hi = -1;
     for (int it = 0; it < 50; it++) {
@@ -1559,7 +1592,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
       if (an == alpha) break;
       alpha = an;
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
-      c.pacc[12] += 1;
+      c.pacc[PH_CNT_LS] += 1;
 #endif
     }
     MJB_STAMP(c, PH_SOL_LS);

@@ -19,3 +19,4 @@ for k, nm in enumerate(names):
     print(f"  {nm:34s} {p[k]:9.0f}  {100*p[k]/tot:5.1f}%")
 print(f"  {'solver:Mv,jv products':34s} {p[15]:9.0f}  {100*p[15]/tot:5.1f}%")
 print(f"  per env-step: line-search iterations {p[12]:.2f}, Newton directions {p[13]:.2f}, Hessian factorisations {p[14]:.2f}")
+print(f"  inside all factorisations (M, M+hD, H): {p[19]:.0f} cycles = load/assembly {p[16]:.0f} + panel loop {p[17]:.0f} + store/back-substitution {p[18]:.0f}")
