@@ -534,32 +534,77 @@ MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane 
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(half == 0 ? p[0] : p[1]);
 }
-template <typename MRef>
-MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
-  const int h = lane >> 5, c = lane & 31, c_ = c;
-  unsigned long long tq0 = pf ? __builtin_amdgcn_s_memtime() : 0;
-  mjb_f16v acc;
-  const float ddiag = (mode == 2 && c < n) ? m.timestep * m.dof_damping[c] : 0.0f;     // one load per lane, added on the diagonal
-  const int cm = c < n ? c : 0;
+// 8 rows of the backward substitution L^T x = y.  rs holds x pre-scaled by the lane's own 1/L_cc, so the serial chain per
+// row is one v_readlane + one FMA.  FULL: every row of the block is < n (no per-row bound checks).
+template <bool FULL>
+MJB_DEV void mfma_back8(const float* Wc, int blk, int n, int c_, float myinv, float& rs) {
+  float lrow[8];
+  int c = c_;
+  asm volatile("" : "+v"(c));
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    int row = 8 * (i >> 2) + 4 * h + (i & 3);
-    float mv = M[(row < n ? row : 0) * n + cm];                                         // unconditional LDS read, then select: no exec-mask branches
-    float v = (row < n && c < n) ? mv : ((row == c) ? 1.0f : 0.0f);
-    acc[i] = row == c ? v + ddiag : v;
-  }
-  if (mode == 1) {
-    for (int r0 = 0; r0 < nefc; r0 += 2) {
-      int rr = r0 + h;
-      float d = rr < nefc ? dw[rr] : 0.0f;
-      float d0 = dw[r0], d1 = (r0 + 1 < nefc) ? dw[r0 + 1] : 0.0f;
-      if (d0 == 0.0f && d1 == 0.0f) continue;                 // uniform: both rows inactive
-      float jv_ = (rr < nefc && c < n) ? J[rr * n + c] : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(d * jv_, jv_, acc, 0, 0, 0);
+  for (int t = 0; t < 8; t++) {
+    const int j = 8 * blk + t;
+    if (FULL) {
+      float lv = Wc[tri_at(j, 0)];                              // L[j][c]; lanes c >= j read past the row: masked
+      lrow[t] = c < j ? lv * myinv : 0.0f;
+    } else {
+      int jj = j < n ? j : n - 1;                               // uniform clamp: rows >= n do not exist in the packed factor
+      float lv = Wc[tri_at(jj, 0)];
+      lrow[t] = (c < j && j < n) ? lv * myinv : 0.0f;
     }
   }
-  float r = (x && c < n) ? x[c] : 0.0f;                       // RHS replicated in both halves (lane -> row c)
+#pragma unroll
+  for (int t = 7; t >= 0; t--) rs -= lrow[t] * rdlane_f(rs, 8 * blk + t);   // rows >= n: lrow == 0 and x_j == 0
+}
+
+template <typename MRef>
+MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c_ = lane & 31;
+  unsigned long long tq0 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  mjb_f16v acc;
+  {
+    // acc[4q+t] of lane (h, c) = A[8q+4h+t][c] = A[c][8q+4h+t] (symmetric): every lane reads along its own row of M,
+    // so the 16 LDS reads use one address register and immediate offsets.  Rows/columns >= n are padded with identity.
+    const int c = c_;
+    const float dadd = c < n ? (mode == 2 ? m.timestep * m.dof_damping[c] : 0.0f) : 1.0f;
+    const float* Mc = M + (c < n ? c : 0) * n + 4 * h;
+    const int nlim = c < n ? n - 4 * h : -1, rdiff = c - 4 * h;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int k = 8 * (i >> 2) + (i & 3);
+      float mv = Mc[k];                                        // may read past row c when 8q+4h+t >= n: masked
+      float v = k < nlim ? mv : 0.0f;
+      acc[i] = k == rdiff ? v + dadd : v;
+    }
+    if (mode == 1) {
+      // Hessian M + J^T D J: one rank-2 MFMA per PAIR OF ACTIVE ROWS (D != 0), the next pair's J loads in flight
+      // while the current MFMA runs.
+      const int cm = c < n ? c : 0;
+      for (int base = 0; base < nefc; base += 64) {
+        const int rix = base + lane;
+        const float dl = rix < nefc ? dw[rix] : 0.0f;
+        unsigned long long act = __ballot(dl != 0.0f);
+        float jcur = 0.0f, dcur = 0.0f;
+        bool have = false;
+        while (act) {
+          int ra = __builtin_ctzll(act); act &= act - 1;
+          int rb = ra; float dB = 0.0f;
+          if (act) { rb = __builtin_ctzll(act); act &= act - 1; dB = rdlane_f(dl, rb); }
+          float dA = rdlane_f(dl, ra);
+          int rr = h == 0 ? ra : rb;
+          float jn = J[(base + rr) * n + cm];
+          float dn = h == 0 ? dA : dB;
+          if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+          jcur = c < n ? jn : 0.0f; dcur = dn; have = true;
+        }
+        if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+      }
+    }
+  }
+  float r = (x && c_ < n) ? x[c_] : 0.0f;                     // RHS replicated in both halves (lane -> row c)
   float myinv = 1.0f;
+  const int wrow = tri_at(c_, 0), cvalid = (h == 0 && c_ < n) ? 0 : -1;
+  const int dump = (int)((dinv + n) - W);                     // one spare word behind dinv swallows the masked stores
   unsigned long long tq1 = pf ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
   for (int jb = 0; jb < 16; jb++) {
@@ -567,53 +612,42 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
     int c = c_;
     asm volatile("" : "+v"(c));                               // keep the per-column lane compares in the loop (cheaper than spilled masks)
-    // column j0 of L = row j0 of the (symmetric) matrix, one entry per lane
-    float v0 = half_bcast(acc[ij], hj);
-    float p0 = t_max(rdlane_f(v0, j0), Num<float>::minval());
-    float inv0 = t_rsqrt(p0);
-    float L0 = c > j0 ? v0 * inv0 : (c == j0 ? p0 * inv0 : 0.0f);
-    if (c == j0) myinv = inv0;
+    // columns j0, j1 of the trailing matrix, one entry per lane; the 2x2 pivot block [a b; b d] is eliminated in scalars
+    // so that the serial chain per panel is rsq -> fma -> rsq
+    float v0 = half_bcast(acc[ij], hj), v1r = half_bcast(acc[ij + 1], hj);
+    float a = __builtin_fmaxf(rdlane_f(v0, j0), Num<float>::minval()), b = rdlane_f(v0, j1), d = rdlane_f(v1r, j1);
+    float inv0 = t_rsqrt(a), bia = b * inv0 * inv0;
+    float d1 = __builtin_fmaxf(d - b * bia, Num<float>::minval());
+    float inv1 = t_rsqrt(d1);
+    float v1 = v1r - bia * v0;
+    float L0 = c > j0 ? v0 * inv0 : (c == j0 ? a * inv0 : 0.0f);
+    float L1 = c > j1 ? v1 * inv1 : (c == j1 ? d1 * inv1 : 0.0f);
+    myinv = c == j0 ? inv0 : (c == j1 ? inv1 : myinv);
+    // fused forward substitution
     float y0 = rdlane_f(r, j0) * inv0;
-    r = c > j0 ? r - L0 * y0 : (c == j0 ? y0 : r);
-    // column j1: first the rank-1 correction from column j0, then the same
-    float v1 = half_bcast(acc[ij + 1], hj) - rdlane_f(L0, j1) * L0;
-    float p1 = t_max(rdlane_f(v1, j1), Num<float>::minval());
-    float inv1 = t_rsqrt(p1);
-    float L1 = c > j1 ? v1 * inv1 : (c == j1 ? p1 * inv1 : 0.0f);
-    if (c == j1) myinv = inv1;
-    float y1 = rdlane_f(r, j1) * inv1;
-    r = c > j1 ? r - L1 * y1 : (c == j1 ? y1 : r);
-    if (h == 0 && c < n) {
-      if (c >= j0 && j0 < n) W[tri_at(c, j0)] = L0;
-      if (c >= j1 && j1 < n) W[tri_at(c, j1)] = L1;
-    }
+    float y1 = (rdlane_f(r, j1) - b * inv0 * y0) * inv1;
+    r = c > j1 ? r - L0 * y0 - L1 * y1 : (c == j1 ? y1 : (c == j0 ? y0 : r));
+    // packed factor to LDS for the backward substitution / later reuse; masked lanes write the dump word
+    int cc = c | cvalid;
+    W[cc >= j0 ? wrow + j0 : dump] = L0;
+    W[cc >= j1 ? wrow + j1 : dump] = L1;
     // rank-2 trailing update of the whole matrix: acc -= [L0 L1] [L0 L1]^T
-    float a = h == 0 ? L0 : L1;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a, a, acc, 0, 0, 0);
+    float av = h == 0 ? L0 : L1;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-av, av, acc, 0, 0, 0);
   }
   unsigned long long tq2 = pf ? __builtin_amdgcn_s_memtime() : 0;
-  if (h == 0 && c < n) dinv[c] = myinv;
+  if (h == 0 && c_ < n) dinv[c_] = myinv;
   gsync<64>();
   if (x) {                                                    // backward substitution L^T x = y from the packed factor in LDS
+    float rs = r * myinv;
+    const float* Wc = W + c_;
 #pragma unroll
-    for (int blk = 3; blk >= 0; blk--) {                        // 8 rows of L^T at a time: bounded register footprint
+    for (int blk = 3; blk >= 0; blk--) {                      // 8 rows of L^T at a time: bounded register footprint
       if (8 * blk >= n) continue;
-      float lrow[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) {
-        int j = 8 * blk + t, jj = j < n ? j : 0;                // always a valid address; masked by the select below
-        float lv = W[tri_at(jj, c < jj ? c : jj)];
-        lrow[t] = (j < n && c < j) ? lv : 0.0f;
-      }
-#pragma unroll
-      for (int t = 7; t >= 0; t--) {
-        int j = 8 * blk + t;
-        if (j >= n) continue;
-        float xj = rdlane_f(r, j) * rdlane_f(myinv, j);
-        r = c == j ? xj : r - lrow[t] * xj;
-      }
+      if (8 * blk + 8 <= n) mfma_back8<true>(Wc, blk, n, c_, myinv, rs);
+      else mfma_back8<false>(Wc, blk, n, c_, myinv, rs);
     }
-    if (h == 0 && c < n) x[c] = r;
+    if (h == 0 && c_ < n) x[c_] = rs;
     gsync<64>();
   }
   if (pf) { unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
