@@ -530,29 +530,29 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
 // ---------------------------------------------------------------------------
 #ifndef MJB_HOST_EMU
 typedef float mjb_f16v __attribute__((ext_vector_type(16)));
+#ifndef MJB_SWEEP_EXCLUDE
+#define MJB_SWEEP_EXCLUDE 1      // factor_W mode that keeps the Cholesky path (1 = Hessian); -1: sweep everywhere
+#endif
 MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane half, column-aligned, in all 64 lanes
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(half == 0 ? p[0] : p[1]);
 }
-// 8 rows of the backward substitution L^T x = y.  rs holds x pre-scaled by the lane's own 1/L_cc, so the serial chain per
-// row is one v_readlane + one FMA.  FULL: every row of the block is < n (no per-row bound checks).
-template <bool FULL>
-MJB_DEV void mfma_back8(const float* Wc, int blk, int n, int c_, float myinv, float& rs) {
-  float lrow[8];
-  int c = c_;
-  asm volatile("" : "+v"(c));
+// Backward substitution L^T x = y, 8 rows at a time.  rs holds x pre-scaled by the lane's own 1/L_cc, so the serial chain
+// per row is one v_readlane + one FMA; the next block's rows are loaded while the current chain runs.
+MJB_DEV void mfma_back_load8(float (&dst)[8], const float* Wc, int blk, int n) {
+  if (8 * blk + 8 <= n) {                                       // every row exists: immediate offsets
 #pragma unroll
-  for (int t = 0; t < 8; t++) {
-    const int j = 8 * blk + t;
-    if (FULL) {
-      float lv = Wc[tri_at(j, 0)];                              // L[j][c]; lanes c >= j read past the row: masked
-      lrow[t] = c < j ? lv * myinv : 0.0f;
-    } else {
-      int jj = j < n ? j : n - 1;                               // uniform clamp: rows >= n do not exist in the packed factor
-      float lv = Wc[tri_at(jj, 0)];
-      lrow[t] = (c < j && j < n) ? lv * myinv : 0.0f;
-    }
+    for (int t = 0; t < 8; t++) dst[t] = Wc[tri_at(8 * blk + t, 0)];     // L[j][c]; lanes c >= j read past the row: masked later
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; t++) { int j = 8 * blk + t, jj = j < n ? j : n - 1; dst[t] = Wc[tri_at(jj, 0)]; }   // uniform clamp
   }
+}
+MJB_DEV void mfma_back_chain8(float (&lrow)[8], int blk, int n, int c_, float myinv, float& rs) {
+  int c = c_;
+  asm volatile("" : "+v"(c), "+v"(lrow[0]), "+v"(lrow[1]), "+v"(lrow[2]), "+v"(lrow[3]), "+v"(lrow[4]), "+v"(lrow[5]), "+v"(lrow[6]), "+v"(lrow[7]));
+#pragma unroll
+  for (int t = 0; t < 8; t++) { const int j = 8 * blk + t; lrow[t] = (c < j && j < n) ? lrow[t] * myinv : 0.0f; }
 #pragma unroll
   for (int t = 7; t >= 0; t--) rs -= lrow[t] * rdlane_f(rs, 8 * blk + t);   // rows >= n: lrow == 0 and x_j == 0
 }
@@ -641,17 +641,112 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
   if (x) {                                                    // backward substitution L^T x = y from the packed factor in LDS
     float rs = r * myinv;
     const float* Wc = W + c_;
+    float cur[8], nxt[8];
+    const int top = (n - 1) >> 3;
+    mfma_back_load8(cur, Wc, top, n);
 #pragma unroll
-    for (int blk = 3; blk >= 0; blk--) {                      // 8 rows of L^T at a time: bounded register footprint
-      if (8 * blk >= n) continue;
-      if (8 * blk + 8 <= n) mfma_back8<true>(Wc, blk, n, c_, myinv, rs);
-      else mfma_back8<false>(Wc, blk, n, c_, myinv, rs);
+    for (int blk = 3; blk >= 0; blk--) {
+      if (blk > top) continue;
+      if (blk > 0) mfma_back_load8(nxt, Wc, blk - 1, n);
+      mfma_back_chain8(cur, blk, n, c_, myinv, rs);
+#pragma unroll
+      for (int t = 0; t < 8; t++) cur[t] = nxt[t];
     }
     if (h == 0 && c_ < n) x[c_] = rs;
     gsync<64>();
   }
   if (pf) { unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
 }
+// x <- A^-1 x for A = M (mode 0), M + J^T D_active J (mode 1, D in dw) or M + h diag(damping) (mode 2), n <= 32, fp32.
+// The symmetric matrix lives in one 32x32 MFMA accumulator (lane (h,c): column c, rows 8q+4h+t) and is inverted in place
+// by the symmetric SWEEP operator, two pivots per v_mfma_f32_32x32x2_f32:
+//     B_ij <- B_ij - U_i P^-1 U_j^T,   B_iP <- U_i P^-1,   B_PP <- -P^-1        (U = columns j0,j1;  P = their 2x2 pivot block)
+// With U' = U - [e_j0 e_j1] the MFMA operands  A_op = -U' P^-1,  B_op = U'^T  produce the pivot rows/columns as well; only the
+// two pivot diagonal entries need a "-2" fix-up.  After all pivots acc = -A^-1 and the solve is a 16-FMA mat-vec per lane:
+// no factor in LDS, no forward/backward substitution chains.  The matrix stays symmetric, so "column j as a lane vector"
+// is one register (+ a half swap) at every step.
+template <typename MRef>
+MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c_ = lane & 31;
+  unsigned long long tq0 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  mjb_f16v acc;
+  {
+    // acc[4q+t] of lane (h, c) = A[8q+4h+t][c] = A[c][8q+4h+t] (symmetric): every lane reads along its own row of M,
+    // so the 16 LDS reads use one address register and immediate offsets.  Rows/columns >= n are padded with identity.
+    const int c = c_;
+    const float dadd = c < n ? (mode == 2 ? m.timestep * m.dof_damping[c] : 0.0f) : 1.0f;
+    const float* Mc = M + (c < n ? c : 0) * n + 4 * h;
+    const int nlim = c < n ? n - 4 * h : -1, rdiff = c - 4 * h;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int k = 8 * (i >> 2) + (i & 3);
+      float mv = Mc[k];                                        // may read past row c when 8q+4h+t >= n: masked
+      float v = k < nlim ? mv : 0.0f;
+      acc[i] = k == rdiff ? v + dadd : v;
+    }
+    if (h == 0) bpad[c] = c < n ? x[c] : 0.0f;                 // right-hand side, zero-padded to 32
+    if (mode == 1) {
+      // Hessian M + J^T D J: one rank-2 MFMA per PAIR OF ACTIVE ROWS (D != 0), the next pair's J loads in flight
+      // while the current MFMA runs.
+      const int cm = c < n ? c : 0;
+      for (int base = 0; base < nefc; base += 64) {
+        const int rix = base + lane;
+        const float dl = rix < nefc ? dw[rix] : 0.0f;
+        unsigned long long act = __ballot(dl != 0.0f);
+        float jcur = 0.0f, dcur = 0.0f;
+        bool have = false;
+        while (act) {
+          int ra = __builtin_ctzll(act); act &= act - 1;
+          int rb = ra; float dB = 0.0f;
+          if (act) { rb = __builtin_ctzll(act); act &= act - 1; dB = rdlane_f(dl, rb); }
+          float dA = rdlane_f(dl, ra);
+          int rr = h == 0 ? ra : rb;
+          float jn = J[(base + rr) * n + cm];
+          float dn = h == 0 ? dA : dB;
+          if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+          jcur = c < n ? jn : 0.0f; dcur = dn; have = true;
+        }
+        if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+      }
+    }
+  }
+  unsigned long long tq1 = pf ? __builtin_amdgcn_s_memtime() : 0;
+#pragma unroll
+  for (int jb = 0; jb < 16; jb++) {
+    const int j0 = 2 * jb, j1 = j0 + 1, hj = (j0 >> 2) & 1, ij = 4 * (j0 >> 3) + (j0 & 3);
+    if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
+    int c = c_, ln = lane;
+    asm volatile("" : "+v"(c), "+v"(ln));                     // keep the per-column lane compares in the loop (cheaper than spilled masks)
+    float u0 = half_bcast(acc[ij], hj), u1 = half_bcast(acc[ij + 1], hj);
+    float a = __builtin_fmaxf(rdlane_f(u0, j0), Num<float>::minval()), b = rdlane_f(u0, j1), d = rdlane_f(u1, j1);
+    float det = __builtin_fmaxf(a * d - b * b, a * Num<float>::minval());
+    float rdet = __builtin_amdgcn_rcpf(det);
+    float p00 = d * rdet, p01 = -b * rdet, p11 = a * rdet;
+    float q0 = h == 0 ? p00 : p01, q1 = h == 0 ? p01 : p11;
+    float u0p = c == j0 ? u0 - 1.0f : u0, u1p = c == j1 ? u1 - 1.0f : u1;
+    float aop = -(u0p * q0 + u1p * q1);
+    float bop = h == 0 ? u0p : u1p;
+    acc[ij] -= ln == 32 * hj + j0 ? 2.0f : 0.0f;
+    acc[ij + 1] -= ln == 32 * hj + j1 ? 2.0f : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc, 0, 0, 0);
+  }
+  unsigned long long tq2 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  gsync<64>();
+  {
+    const float* bp = bpad + 4 * h;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { s0 += acc[t] * bp[t]; s1 += acc[4 + t] * bp[8 + t]; s2 += acc[8 + t] * bp[16 + t]; s3 += acc[12 + t] * bp[24 + t]; }
+    float s = (s0 + s1) + (s2 + s3);
+    auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    float tot = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    if (h == 0 && c_ < n) x[c_] = -tot;                       // acc = -A^-1
+    gsync<64>();
+  }
+  if (pf) { unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
+}
+template <typename MRef>
+MJB_DEV void mfma_sweep_solve32(MRef, const double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 template <typename MRef>
 MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 #endif
@@ -659,6 +754,14 @@ MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*,
 // W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
 // If x != nullptr the system (factor) x = x is solved in the same pass (fused on the register path).
 template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* x);
+// true where factor_W() inverts-and-solves in registers (fp32, one wave per environment, nv <= 32) and leaves NO factor in W
+template <typename T, int G> MJB_DEV bool fused_inverse_path(int nv) {
+#ifndef MJB_HOST_EMU
+  return G == 64 && sizeof(T) == 4 && nv <= 32;
+#else
+  return false;
+#endif
+}
 template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -674,11 +777,15 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
   if (G == 64) {
 #ifndef MJB_HOST_EMU
     if (nv <= 32) {
+      // M and M + hD are well conditioned: in-register sweep inverse.  The Hessian (contact stiffness on a few dofs) keeps
+      // the backward-stable Cholesky, whose packed factor in W is reused while the active set does not change.
 #if defined(MJB_PROFILE)
-      if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x, c.pacc + PH_FAC_LOAD);
+      unsigned long long* pf = c.pacc + PH_FAC_LOAD;
 #else
-      if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
+      unsigned long long* pf = nullptr;
 #endif
+      if (sizeof(T) == 4 && mode != MJB_SWEEP_EXCLUDE) mfma_sweep_solve32<ModelRef<T>>(m, M, w + L.tmp, J, dw, nefc, mode, nv, lane, x, pf);
+      else if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x, pf);
       else reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
       return;
     }
@@ -1551,7 +1658,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
     gpart += g * g;
   }
   T gn = gsum<T, G>(gpart);
-  const bool rebuild = gsumi<G>(chg) != 0;
+  const bool rebuild = (MJB_SWEEP_EXCLUDE != 1 && fused_inverse_path<T, G>(nv)) || gsumi<G>(chg) != 0;   // the sweep path keeps no factor
   gsync<G>();
   if (gn < gtol2) return gn;
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)

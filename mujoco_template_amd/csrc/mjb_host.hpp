@@ -228,7 +228,7 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   L.M = A(nv * nv); L.W = A(nv * (nv + 1) / 2); L.ten_length = A(nt); L.ten_J = A(nt * nv); L.act_force = A(nu); L.sens = A(h.nsensordata);
   L.con = A(ncon_max * CON_STRIDE);
   L.efc_J = A(nefc_max * nv); L.efc_pos = A(nefc_max); L.efc_D = A(nefc_max); L.efc_aref = A(nefc_max);
-  L.tmp = A(nv + 1);                         // +1: dump word for the masked stores of the MFMA factorisation
+  L.tmp = A(nv > 32 ? nv + 1 : 33);          // 1/diag(L) + one dump word; also the zero-padded right-hand side of the 32x32 MFMA solve
   if (h.has_accel) L.cacc = A(6 * nb);          // accelerometers read the bias acceleration after the solve: keep it out of the overlay
   // One overlay region for temporaries with disjoint lifetimes (forward() order: kinematics, com_pos, collision,
   // crb, make_constraint, velocity stage, actuation, solver):
