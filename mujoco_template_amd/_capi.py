@@ -19,7 +19,7 @@ from .exceptions import ConfigError, NameLookupError, TemplateError
 from .mjcf import CompiledModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmjbatch_prof.so" if os.environ.get("MJB_PROFILE") == "1" else "libmjbatch.so")
+_LIB_PATH = os.environ.get("MJB_LIB") or os.path.join(_HERE, "libmjbatch_prof.so" if os.environ.get("MJB_PROFILE") == "1" else "libmjbatch.so")
 _LIB: ctypes.CDLL | None = None
 
 MJB_F32, MJB_F64 = 0, 1

@@ -528,11 +528,11 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
 // one MFMA per pair of constraint rows.  Forward substitution is fused; L goes to LDS (packed) for the
 // backward substitution and for reuse when the active set does not change.
 // ---------------------------------------------------------------------------
-#ifndef MJB_HOST_EMU
-typedef float mjb_f16v __attribute__((ext_vector_type(16)));
 #ifndef MJB_SWEEP_EXCLUDE
 #define MJB_SWEEP_EXCLUDE 1      // factor_W mode that keeps the Cholesky path (1 = Hessian); -1: sweep everywhere
 #endif
+#ifndef MJB_HOST_EMU
+typedef float mjb_f16v __attribute__((ext_vector_type(16)));
 MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane half, column-aligned, in all 64 lanes
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(half == 0 ? p[0] : p[1]);
@@ -815,6 +815,18 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
 // ---------------------------------------------------------------------------
 // A1 kinematics: tree levels in order, bodies of a level across lanes
 // ---------------------------------------------------------------------------
+// rotate v by the unit quaternion q (through the rotation matrix, like the per-body frames)
+template <typename T> MJB_DEV void quat_rot(T* r, const T* q, const T* v) {
+  T R[9];
+  quat2mat(R, q);
+  mulmatvec3(r, R, v);
+}
+
+// Three stages instead of one long per-level body loop (only a few lanes are active per tree level):
+//   (1) all bodies in parallel: pose of the body RELATIVE TO ITS PARENT (joint chain applied in the parent frame), and
+//       the joints' anchors / axes in the parent frame;
+//   (2) per tree level: compose with the parent's world pose (one quaternion product + one rotation per body);
+//   (3) all bodies / joints in parallel: xmat, inertial frames, world anchors and axes.
 template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
   MJB_ENV(c); T* w = c.w; const int lane = c.lane;
   T *xpos = w + L.xpos, *xquat = w + L.xquat, *xmat = w + L.xmat, *xipos = w + L.xipos, *ximat = w + L.ximat;
@@ -825,73 +837,102 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
 #pragma unroll
     for (int k = 0; k < 9; k++) { xmat[k] = (k % 4 == 0) ? (T)1 : (T)0; ximat[k] = xmat[k]; }
   }
-  gsync<G>();
-  for (int lev = 0; lev < m.nlevel; lev++) {
-    int a0 = m.level_adr[lev], a1 = m.level_adr[lev + 1];
-    for (int idx = a0 + lane; idx < a1; idx += G) {
-      int b = m.level_body[idx], p = m.body_parentid[b], jadr = m.body_jntadr[b], jnum = m.body_jntnum[b];
-      T pos[3], quat[4], R[9];
-      if (jnum == 1 && m.jnt_type[jadr] == JNT_FREE) {
-        int qa = m.jnt_qposadr[jadr];
-        quat[0] = qpos[qa + 3]; quat[1] = qpos[qa + 4]; quat[2] = qpos[qa + 5]; quat[3] = qpos[qa + 6];
-        quat_normalize(quat);
-        qpos[qa + 3] = quat[0]; qpos[qa + 4] = quat[1]; qpos[qa + 5] = quat[2]; qpos[qa + 6] = quat[3];
-        pos[0] = qpos[qa]; pos[1] = qpos[qa + 1]; pos[2] = qpos[qa + 2];
-        xanchor[3 * jadr] = pos[0]; xanchor[3 * jadr + 1] = pos[1]; xanchor[3 * jadr + 2] = pos[2];
-        xaxis[3 * jadr] = 0; xaxis[3 * jadr + 1] = 0; xaxis[3 * jadr + 2] = 1;
-      } else {
-        T bp[3] = {m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]};
-        T bq[4] = {m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]};
-        T pm[9], pq[4];
+  // (1) local poses; xpos/xquat/xanchor/xaxis temporarily hold parent-frame values
+  for (int b = 1 + lane; b < m.nbody; b += G) {
+    int jadr = m.body_jntadr[b], jnum = m.body_jntnum[b];
+    T pos[3], quat[4], R[9];
+    if (jnum == 1 && m.jnt_type[jadr] == JNT_FREE) {
+      int qa = m.jnt_qposadr[jadr];
+      quat[0] = qpos[qa + 3]; quat[1] = qpos[qa + 4]; quat[2] = qpos[qa + 5]; quat[3] = qpos[qa + 6];
+      quat_normalize(quat);
+      qpos[qa + 3] = quat[0]; qpos[qa + 4] = quat[1]; qpos[qa + 5] = quat[2]; qpos[qa + 6] = quat[3];
+      pos[0] = qpos[qa]; pos[1] = qpos[qa + 1]; pos[2] = qpos[qa + 2];
+      xanchor[3 * jadr] = pos[0]; xanchor[3 * jadr + 1] = pos[1]; xanchor[3 * jadr + 2] = pos[2];
+      xaxis[3 * jadr] = 0; xaxis[3 * jadr + 1] = 0; xaxis[3 * jadr + 2] = 1;
+    } else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) pm[k] = xmat[9 * p + k];
+      for (int k = 0; k < 3; k++) pos[k] = m.body_pos[3 * b + k];
 #pragma unroll
-        for (int k = 0; k < 4; k++) pq[k] = xquat[4 * p + k];
-        mulmatvec3(pos, pm, bp);
-        pos[0] += xpos[3 * p]; pos[1] += xpos[3 * p + 1]; pos[2] += xpos[3 * p + 2];
-        quat_mul(quat, pq, bq);
-        for (int j = jadr; j < jadr + jnum; j++) {
-          T jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
-          T ja[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
-          T anchor[3], axis[3];
-          quat2mat(R, quat);
-          mulmatvec3(anchor, R, jp);
-          anchor[0] += pos[0]; anchor[1] += pos[1]; anchor[2] += pos[2];
-          mulmatvec3(axis, R, ja);
-          xanchor[3 * j] = anchor[0]; xanchor[3 * j + 1] = anchor[1]; xanchor[3 * j + 2] = anchor[2];
-          xaxis[3 * j] = axis[0]; xaxis[3 * j + 1] = axis[1]; xaxis[3 * j + 2] = axis[2];
-          int qa = m.jnt_qposadr[j];
-          T val = qpos[qa] - m.qpos0[qa];
-          if (m.jnt_type[j] == JNT_SLIDE) {
-            pos[0] += axis[0] * val; pos[1] += axis[1] * val; pos[2] += axis[2] * val;
-          } else {
-            T ql[4], qn[4], v[3];
-            axisangle2quat(ql, ja, val);
-            quat_mul(qn, quat, ql);
-            quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-            quat2mat(R, quat);
-            mulmatvec3(v, R, jp);
-            pos[0] = anchor[0] - v[0]; pos[1] = anchor[1] - v[1]; pos[2] = anchor[2] - v[2];
-          }
+      for (int k = 0; k < 4; k++) quat[k] = m.body_quat[4 * b + k];
+      for (int j = jadr; j < jadr + jnum; j++) {
+        T jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
+        T ja[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
+        int qa = m.jnt_qposadr[j];
+        T val = qpos[qa] - m.qpos0[qa];
+        T anchor[3], axis[3];
+        quat2mat(R, quat);
+        mulmatvec3(anchor, R, jp);
+        anchor[0] += pos[0]; anchor[1] += pos[1]; anchor[2] += pos[2];
+        mulmatvec3(axis, R, ja);
+        xanchor[3 * j] = anchor[0]; xanchor[3 * j + 1] = anchor[1]; xanchor[3 * j + 2] = anchor[2];
+        xaxis[3 * j] = axis[0]; xaxis[3 * j + 1] = axis[1]; xaxis[3 * j + 2] = axis[2];
+        if (m.jnt_type[j] == JNT_SLIDE) {
+          pos[0] += axis[0] * val; pos[1] += axis[1] * val; pos[2] += axis[2] * val;
+        } else {
+          T ql[4], qn[4], v[3];
+          axisangle2quat(ql, ja, val);
+          quat_mul(qn, quat, ql);
+          quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+          quat_rot(v, quat, jp);
+          pos[0] = anchor[0] - v[0]; pos[1] = anchor[1] - v[1]; pos[2] = anchor[2] - v[2];
         }
       }
-      quat_normalize(quat);
-      quat2mat(R, quat);
-      T ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]};
-      T iq[4] = {m.body_iquat[4 * b], m.body_iquat[4 * b + 1], m.body_iquat[4 * b + 2], m.body_iquat[4 * b + 3]};
-      T t[3], q2[4], R2[9];
-      mulmatvec3(t, R, ip);
-      quat_mul(q2, quat, iq);
-      quat2mat(R2, q2);
+    }
 #pragma unroll
-      for (int k = 0; k < 3; k++) { xpos[3 * b + k] = pos[k]; xipos[3 * b + k] = pos[k] + t[k]; }
+    for (int k = 0; k < 3; k++) xpos[3 * b + k] = pos[k];
 #pragma unroll
-      for (int k = 0; k < 4; k++) xquat[4 * b + k] = quat[k];
+    for (int k = 0; k < 4; k++) xquat[4 * b + k] = quat[k];
+  }
+  gsync<G>();
+  // (2) compose down the tree, in place
+  for (int lev = 1; lev <= m.nlevel; lev++) {
+    for (int b = 1 + lane; b < m.nbody; b += G) {
+      if (m.body_depth[b] != lev) continue;
+      int p = m.body_parentid[b];
+      T pq[4], pp[3], lq[4], lp[3], q[4], t[3];
 #pragma unroll
-      for (int k = 0; k < 9; k++) { xmat[9 * b + k] = R[k]; ximat[9 * b + k] = R2[k]; }
+      for (int k = 0; k < 4; k++) { pq[k] = xquat[4 * p + k]; lq[k] = xquat[4 * b + k]; }
+#pragma unroll
+      for (int k = 0; k < 3; k++) { pp[k] = xpos[3 * p + k]; lp[k] = xpos[3 * b + k]; }
+      quat_mul(q, pq, lq);
+      quat_normalize(q);
+      quat_rot(t, pq, lp);
+#pragma unroll
+      for (int k = 0; k < 4; k++) xquat[4 * b + k] = q[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) xpos[3 * b + k] = pp[k] + t[k];
     }
     gsync<G>();
   }
+  // (3) frames of the bodies and world anchors / axes of the joints (read the PARENT pose: already final)
+  for (int b = 1 + lane; b < m.nbody; b += G) {
+    T quat[4], R[9], t[3], q2[4], R2[9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) quat[k] = xquat[4 * b + k];
+    quat2mat(R, quat);
+    T ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]};
+    T iq[4] = {m.body_iquat[4 * b], m.body_iquat[4 * b + 1], m.body_iquat[4 * b + 2], m.body_iquat[4 * b + 3]};
+    mulmatvec3(t, R, ip);
+    quat_mul(q2, quat, iq);
+    quat2mat(R2, q2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) xipos[3 * b + k] = xpos[3 * b + k] + t[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { xmat[9 * b + k] = R[k]; ximat[9 * b + k] = R2[k]; }
+  }
+  for (int j = lane; j < m.njnt; j += G) {
+    if (m.jnt_type[j] == JNT_FREE) continue;                    // already world values (the parent is the world body)
+    int p = m.body_parentid[m.jnt_bodyid[j]];
+    T pq[4], R[9], a[3], ax[3], la[3] = {xanchor[3 * j], xanchor[3 * j + 1], xanchor[3 * j + 2]}, lx[3] = {xaxis[3 * j], xaxis[3 * j + 1], xaxis[3 * j + 2]};
+#pragma unroll
+    for (int k = 0; k < 4; k++) pq[k] = xquat[4 * p + k];
+    quat2mat(R, pq);
+    mulmatvec3(a, R, la);
+    mulmatvec3(ax, R, lx);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { xanchor[3 * j + k] = xpos[3 * p + k] + a[k]; xaxis[3 * j + k] = ax[k]; }
+  }
+  gsync<G>();
   T *gx = w + L.geom_xpos, *gm = w + L.geom_xmat, *sx = w + L.site_xpos, *sm = w + L.site_xmat;
   for (int g = lane; g < m.ngeom + m.nsite; g += G) {
     bool is_geom = g < m.ngeom;
@@ -1420,55 +1461,93 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
     cacc[0] = cacc[1] = cacc[2] = 0; cacc[3] = -m.gravity[0]; cacc[4] = -m.gravity[1]; cacc[5] = -m.gravity[2];
   }
   gsync<G>();
-  for (int lev = 0; lev < m.nlevel; lev++) {
-    for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
-      int b = m.level_body[idx], p = m.body_parentid[b], da = m.body_dofadr[b], dn = m.body_dofnum[b];
-      T cv[6], ca[6], tmp[6];
+  // Spatial velocities / bias accelerations are sums over the ancestor dofs (everything is expressed at the subtree COM of
+  // the root).  Per-body increments are formed in parallel, the per-level loops only add the parent's total:
+  //   (1) cvel[b] <- sum of the body's own cdof*qvel                  (all bodies)
+  //   (2) cvel[b] += cvel[parent]                                     (per level)
+  //   (3) cdof_dot[j] = (velocity just before dof j) x cdof[j]        (all dofs)
+  //   (4) cacc[b] <- sum of the body's own cdof_dot*qvel              (all bodies)
+  //   (5) cacc[b] += cacc[parent]                                     (per level)
+  //   (6) cfrc[b] = I cacc + cvel x* (I cvel)                         (all bodies)
+  for (int b = 1 + lane; b < m.nbody; b += G) {
+    int da = m.body_dofadr[b], dn = m.body_dofnum[b];
+    T dv[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = da; j < da + dn; j++) {
+      T qv = qvel[j];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { cv[k] = cvel[6 * p + k]; ca[k] = cacc[6 * p + k]; }
-      for (int j = da; j < da + dn;) {
-        int jt = m.jnt_type[m.dof_jntid[j]];
-        if (jt == JNT_FREE) {
-          for (int k = 0; k < 3; k++) {
+      for (int q = 0; q < 6; q++) dv[q] += cdof[6 * j + q] * qv;
+    }
 #pragma unroll
-            for (int q = 0; q < 6; q++) { cdd[6 * (j + k) + q] = 0; cv[q] += cdof[6 * (j + k) + q] * qvel[j + k]; }
-          }
-          j += 3;
-          for (int k = 0; k < 3; k++) {
-            T cd[6];
+    for (int q = 0; q < 6; q++) cvel[6 * b + q] = dv[q];
+  }
+  gsync<G>();
+  for (int lev = 2; lev <= m.nlevel; lev++) {                   // depth-1 bodies hang off the (motionless) world body
+    for (int b = 1 + lane; b < m.nbody; b += G) {
+      if (m.body_depth[b] != lev) continue;
+      int p = m.body_parentid[b];
 #pragma unroll
-            for (int q = 0; q < 6; q++) cd[q] = cdof[6 * (j + k) + q];
-            cross_motion(tmp, cv, cd);
-#pragma unroll
-            for (int q = 0; q < 6; q++) { cdd[6 * (j + k) + q] = tmp[q]; ca[q] += tmp[q] * qvel[j + k]; }
-          }
-          for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) cv[q] += cdof[6 * (j + k) + q] * qvel[j + k];
-          }
-          j += 3;
-        } else {
-          T cd[6];
-#pragma unroll
-          for (int q = 0; q < 6; q++) cd[q] = cdof[6 * j + q];
-          cross_motion(tmp, cv, cd);
-          T qv = qvel[j];
-#pragma unroll
-          for (int q = 0; q < 6; q++) { cdd[6 * j + q] = tmp[q]; ca[q] += tmp[q] * qv; cv[q] += cd[q] * qv; }
-          j++;
-        }
-      }
-      T in[10], f[6], t1[6], t2[6];
-#pragma unroll
-      for (int k = 0; k < 10; k++) in[k] = cin[10 * b + k];
-      mul_inert_vec(f, in, ca);
-      mul_inert_vec(t1, in, cv);
-      cross_force(t2, cv, t1);
-#pragma unroll
-      for (int k = 0; k < 6; k++) { cvel[6 * b + k] = cv[k]; cacc[6 * b + k] = ca[k]; cfrc[6 * b + k] = f[k] + t2[k]; }
+      for (int q = 0; q < 6; q++) cvel[6 * b + q] += cvel[6 * p + q];
     }
     gsync<G>();
   }
+  for (int j = lane; j < nv; j += G) {
+    int b = m.dof_bodyid[j], p = m.body_parentid[b], jn = m.dof_jntid[j], jd = m.jnt_dofadr[jn];
+    const bool isfree = m.jnt_type[jn] == JNT_FREE;
+    T tmp[6] = {0, 0, 0, 0, 0, 0};
+    if (!(isfree && j < jd + 3)) {                              // translational dofs of a free joint: cdof_dot = 0
+      const int gs = isfree ? jd + 3 : j;                       // the three rotations of a free joint share the velocity after its translations
+      T cv[6], cd[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) { cv[q] = cvel[6 * p + q]; cd[q] = cdof[6 * j + q]; }
+      for (int k = m.body_dofadr[b]; k < gs; k++) {
+        T qv = qvel[k];
+#pragma unroll
+        for (int q = 0; q < 6; q++) cv[q] += cdof[6 * k + q] * qv;
+      }
+      cross_motion(tmp, cv, cd);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) cdd[6 * j + q] = tmp[q];
+  }
+  gsync<G>();
+  for (int b = 1 + lane; b < m.nbody; b += G) {
+    int da = m.body_dofadr[b], dn = m.body_dofnum[b];
+    T da6[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = da; j < da + dn; j++) {
+      T qv = qvel[j];
+#pragma unroll
+      for (int q = 0; q < 6; q++) da6[q] += cdd[6 * j + q] * qv;
+    }
+    if (m.body_depth[b] == 1) {                                  // children of the world body start from -gravity
+#pragma unroll
+      for (int q = 0; q < 6; q++) da6[q] += cacc[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) cacc[6 * b + q] = da6[q];
+  }
+  gsync<G>();
+  for (int lev = 2; lev <= m.nlevel; lev++) {
+    for (int b = 1 + lane; b < m.nbody; b += G) {
+      if (m.body_depth[b] != lev) continue;
+      int p = m.body_parentid[b];
+#pragma unroll
+      for (int q = 0; q < 6; q++) cacc[6 * b + q] += cacc[6 * p + q];
+    }
+    gsync<G>();
+  }
+  for (int b = 1 + lane; b < m.nbody; b += G) {
+    T in[10], cv[6], ca[6], f[6], t1[6], t2[6];
+#pragma unroll
+    for (int k = 0; k < 10; k++) in[k] = cin[10 * b + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cv[k] = cvel[6 * b + k]; ca[k] = cacc[6 * b + k]; }
+    mul_inert_vec(f, in, ca);
+    mul_inert_vec(t1, in, cv);
+    cross_force(t2, cv, t1);
+#pragma unroll
+    for (int k = 0; k < 6; k++) cfrc[6 * b + k] = f[k] + t2[k];
+  }
+  gsync<G>();
   for (int lev = m.nlevel - 1; lev >= 0; lev--) {
     for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
       int b = m.level_body[idx];

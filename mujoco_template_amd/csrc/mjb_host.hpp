@@ -187,7 +187,7 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
     return (FP)alloc.putf(tv);
   };
   auto Iq = [&](const char* k) -> IP { return (IP)alloc.puti(h.I(k)); };
-  m.body_parentid = Iq("body_parentid"); m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
+  m.body_parentid = Iq("body_parentid"); m.body_depth = Iq("body_depth"); m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
   m.body_dofadr = Iq("body_dofadr"); m.body_dofnum = Iq("body_dofnum");
   m.level_adr = (IP)alloc.puti(h.level_adr); m.level_body = (IP)alloc.puti(h.level_body); m.child_adr = (IP)alloc.puti(h.child_adr); m.child_id = (IP)alloc.puti(h.child_id); m.tri_tab = (IP)alloc.puti(h.tri_tab);
   m.dofact_adr = (IP)alloc.puti(h.dofact_adr); m.dofact_act = (IP)alloc.puti(h.dofact_act); m.siteact = (IP)alloc.puti(h.siteact); m.mpair = (IP)alloc.puti(h.mpair);

@@ -9,8 +9,11 @@
 
 namespace mjb {
 
+#ifndef MJB_WPS
+#define MJB_WPS 2        // waves per SIMD the register budget of k_step is sized for (LDS fixes the real occupancy)
+#endif
 template <typename T, typename TS, int G>
-__global__ __launch_bounds__(64, 2) void k_step(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
+__global__ __launch_bounds__(64, MJB_WPS) void k_step(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
   extern __shared__ __align__(16) char smem[];
   const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
   const int env = blockIdx.x * (64 / G) + sub;

@@ -39,7 +39,7 @@ struct DevModel {
   int ncon_max, nefc_max, nsiteact, nmpair;
   T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
   // kinematic tree
-  IP body_parentid, body_rootid, body_jntadr, body_jntnum, body_dofadr, body_dofnum;
+  IP body_parentid, body_rootid, body_jntadr, body_jntnum, body_dofadr, body_dofnum, body_depth;
   IP level_adr, level_body, child_adr, child_id, tri_tab;
   IP dofact_adr, dofact_act, siteact, mpair;   // joint-transmission actuators per dof (CSR), site-transmission actuators, (i<<8|j) ancestor dof pairs of M
   FP body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_subtreemass, body_invweight0;
