@@ -35,7 +35,14 @@ namespace mjb {
 // group primitives
 // ---------------------------------------------------------------------------
 #ifndef MJB_HOST_EMU
-template <int G> MJB_DEV void gsync() { __syncthreads(); }   // block == one wavefront: lowers to a wave barrier
+// Every kernel runs ONE wavefront per workgroup and an environment never spans waves, so a group sync only has to order
+// the wave's own LDS traffic.  DS instructions of a wave execute in issue order: a wavefront-scope fence (a compiler
+// ordering point, no s_waitcnt vmcnt(0)/s_barrier) is enough, and outstanding global/constant loads stay in flight.
+template <int G> MJB_DEV void gsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // DPP lane permutations inside a 16-lane row (no LDS traffic): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E,
 // row_half_mirror = 0x141, row_mirror = 0x140.  After the four steps every lane of a row holds the row total.
@@ -815,6 +822,57 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
 // ---------------------------------------------------------------------------
 // A1 kinematics: tree levels in order, bodies of a level across lanes
 // ---------------------------------------------------------------------------
+// arr[b] += arr[parent] down the tree (velocities, bias accelerations): depth and parent of the lane's body in registers
+template <typename T, int G, int NC> MJB_DEV void tree_forward_sum(Ctx<T>& c, T* arr) {
+  MJB_ENV(c); const int lane = c.lane;
+  const int b0 = 1 + lane;
+  int dep0 = -1, par0 = 0;
+  if (b0 < m.nbody) { dep0 = m.body_depth[b0]; par0 = m.body_parentid[b0]; }
+  for (int lev = 2; lev <= m.nlevel; lev++) {                   // depth-1 bodies hang off the world body: nothing to add / added by the caller
+    for (int b = b0; b < m.nbody; b += G) {
+      const int dep = b == b0 ? dep0 : m.body_depth[b];
+      if (dep != lev) continue;
+      const int p = b == b0 ? par0 : m.body_parentid[b];
+      T pa[NC], ch[NC];
+#pragma unroll
+      for (int q = 0; q < NC; q++) { pa[q] = arr[NC * p + q]; ch[q] = arr[NC * b + q]; }
+#pragma unroll
+      for (int q = 0; q < NC; q++) arr[NC * b + q] = ch[q] + pa[q];
+    }
+    gsync<G>();
+  }
+}
+
+// Subtree sums (subtree COM, composite inertias, subtree forces): every body adds its NC-vector into its parent.
+// Bodies are scheduled in "rounds" (host: deepest level first, one sibling rank per round) so that no two bodies of a
+// round share a parent and every body is complete before it is added.  The lane's body, round and parent stay in
+// registers: one round = LDS read-add-write, no index tables on the critical path.
+template <typename T, int G, int NC> MJB_DEV void tree_backward_sum(Ctx<T>& c, T* arr, int nrounds) {
+  MJB_ENV(c); const int lane = c.lane;
+  const int b0 = 1 + lane;
+  int rd0 = -1, p0 = 0;
+  if (b0 < m.nbody) { rd0 = m.body_round[b0]; p0 = m.body_parentid[b0]; }
+  for (int rd = 0; rd < nrounds; rd++) {
+    if (rd0 == rd) {                                            // all loads first: the stores may alias them for the compiler
+      T pa[NC], ch[NC];
+#pragma unroll
+      for (int k = 0; k < NC; k++) { pa[k] = arr[NC * p0 + k]; ch[k] = arr[NC * b0 + k]; }
+#pragma unroll
+      for (int k = 0; k < NC; k++) arr[NC * p0 + k] = pa[k] + ch[k];
+    }
+    for (int b = b0 + G; b < m.nbody; b += G) {                 // models with more bodies than lanes
+      if (m.body_round[b] != rd) continue;
+      int p = m.body_parentid[b];
+      T pa[NC], ch[NC];
+#pragma unroll
+      for (int k = 0; k < NC; k++) { pa[k] = arr[NC * p + k]; ch[k] = arr[NC * b + k]; }
+#pragma unroll
+      for (int k = 0; k < NC; k++) arr[NC * p + k] = pa[k] + ch[k];
+    }
+    gsync<G>();
+  }
+}
+
 // rotate v by the unit quaternion q (through the rotation matrix, like the per-body frames)
 template <typename T> MJB_DEV void quat_rot(T* r, const T* q, const T* v) {
   T R[9];
@@ -885,24 +943,30 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
   }
   gsync<G>();
   // (2) compose down the tree, in place
-  for (int lev = 1; lev <= m.nlevel; lev++) {
-    for (int b = 1 + lane; b < m.nbody; b += G) {
-      if (m.body_depth[b] != lev) continue;
-      int p = m.body_parentid[b];
-      T pq[4], pp[3], lq[4], lp[3], q[4], t[3];
+  {
+    const int b0 = 1 + lane;
+    int dep0 = -1, par0 = 0;                                    // the lane's body: depth and parent stay in registers
+    if (b0 < m.nbody) { dep0 = m.body_depth[b0]; par0 = m.body_parentid[b0]; }
+    for (int lev = 1; lev <= m.nlevel; lev++) {
+      for (int b = b0; b < m.nbody; b += G) {
+        const int dep = b == b0 ? dep0 : m.body_depth[b];
+        if (dep != lev) continue;
+        const int p = b == b0 ? par0 : m.body_parentid[b];
+        T pq[4], pp[3], lq[4], lp[3], q[4], t[3];
 #pragma unroll
-      for (int k = 0; k < 4; k++) { pq[k] = xquat[4 * p + k]; lq[k] = xquat[4 * b + k]; }
+        for (int k = 0; k < 4; k++) { pq[k] = xquat[4 * p + k]; lq[k] = xquat[4 * b + k]; }
 #pragma unroll
-      for (int k = 0; k < 3; k++) { pp[k] = xpos[3 * p + k]; lp[k] = xpos[3 * b + k]; }
-      quat_mul(q, pq, lq);
-      quat_normalize(q);
-      quat_rot(t, pq, lp);
+        for (int k = 0; k < 3; k++) { pp[k] = xpos[3 * p + k]; lp[k] = xpos[3 * b + k]; }
+        quat_mul(q, pq, lq);
+        quat_normalize(q);
+        quat_rot(t, pq, lp);
 #pragma unroll
-      for (int k = 0; k < 4; k++) xquat[4 * b + k] = q[k];
+        for (int k = 0; k < 4; k++) xquat[4 * b + k] = q[k];
 #pragma unroll
-      for (int k = 0; k < 3; k++) xpos[3 * b + k] = pp[k] + t[k];
+        for (int k = 0; k < 3; k++) xpos[3 * b + k] = pp[k] + t[k];
+      }
+      gsync<G>();
     }
-    gsync<G>();
   }
   // (3) frames of the bodies and world anchors / axes of the joints (read the PARENT pose: already final)
   for (int b = 1 + lane; b < m.nbody; b += G) {
@@ -971,19 +1035,7 @@ template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
     for (int k = 0; k < 3; k++) sc[3 * b + k] = ms * xipos[3 * b + k];
   }
   gsync<G>();
-  for (int lev = m.nlevel - 1; lev >= -1; lev--) {      // lev == -1: the world body
-    int a0 = lev >= 0 ? m.level_adr[lev] : 0, a1 = lev >= 0 ? m.level_adr[lev + 1] : 1;
-    for (int idx = a0 + lane; idx < a1; idx += G) {
-      int b = lev >= 0 ? m.level_body[idx] : 0;
-      T s[3] = {sc[3 * b], sc[3 * b + 1], sc[3 * b + 2]};
-      for (int ci = m.child_adr[b]; ci < m.child_adr[b + 1]; ci++) {
-        int ch = m.child_id[ci];
-        s[0] += sc[3 * ch]; s[1] += sc[3 * ch + 1]; s[2] += sc[3 * ch + 2];
-      }
-      sc[3 * b] = s[0]; sc[3 * b + 1] = s[1]; sc[3 * b + 2] = s[2];
-    }
-    gsync<G>();
-  }
+  tree_backward_sum<T, G, 3>(c, sc, m.nround);              // includes the world body's subtree (everything)
   for (int b = lane; b < m.nbody; b += G) {
     T sm = m.body_subtreemass[b];
     if (sm < Num<T>::minval()) { sc[3 * b] = xipos[3 * b]; sc[3 * b + 1] = xipos[3 * b + 1]; sc[3 * b + 2] = xipos[3 * b + 2]; }
@@ -1069,23 +1121,7 @@ template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
   T *crb = w + L.crb, *cin = w + L.cinert, *cdof = w + L.cdof, *buf = w + L.dofbuf, *M = w + L.M, *W = w + L.W;
   for (int i = lane; i < 10 * m.nbody; i += G) crb[i] = cin[i];
   gsync<G>();
-  for (int lev = m.nlevel - 1; lev >= 0; lev--) {
-    for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
-      int b = m.level_body[idx];
-      if (m.child_adr[b] == m.child_adr[b + 1]) continue;
-      T s[10];
-#pragma unroll
-      for (int k = 0; k < 10; k++) s[k] = crb[10 * b + k];
-      for (int ci = m.child_adr[b]; ci < m.child_adr[b + 1]; ci++) {
-        int ch = m.child_id[ci];
-#pragma unroll
-        for (int k = 0; k < 10; k++) s[k] += crb[10 * ch + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 10; k++) crb[10 * b + k] = s[k];
-    }
-    gsync<G>();
-  }
+  tree_backward_sum<T, G, 10>(c, crb, m.nround_inner);
   for (int i = lane; i < nv; i += G) {
     T in[10], v[6], r[6];
     int b = m.dof_bodyid[i];
@@ -1481,15 +1517,7 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
     for (int q = 0; q < 6; q++) cvel[6 * b + q] = dv[q];
   }
   gsync<G>();
-  for (int lev = 2; lev <= m.nlevel; lev++) {                   // depth-1 bodies hang off the (motionless) world body
-    for (int b = 1 + lane; b < m.nbody; b += G) {
-      if (m.body_depth[b] != lev) continue;
-      int p = m.body_parentid[b];
-#pragma unroll
-      for (int q = 0; q < 6; q++) cvel[6 * b + q] += cvel[6 * p + q];
-    }
-    gsync<G>();
-  }
+  tree_forward_sum<T, G, 6>(c, cvel);
   for (int j = lane; j < nv; j += G) {
     int b = m.dof_bodyid[j], p = m.body_parentid[b], jn = m.dof_jntid[j], jd = m.jnt_dofadr[jn];
     const bool isfree = m.jnt_type[jn] == JNT_FREE;
@@ -1526,15 +1554,7 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
     for (int q = 0; q < 6; q++) cacc[6 * b + q] = da6[q];
   }
   gsync<G>();
-  for (int lev = 2; lev <= m.nlevel; lev++) {
-    for (int b = 1 + lane; b < m.nbody; b += G) {
-      if (m.body_depth[b] != lev) continue;
-      int p = m.body_parentid[b];
-#pragma unroll
-      for (int q = 0; q < 6; q++) cacc[6 * b + q] += cacc[6 * p + q];
-    }
-    gsync<G>();
-  }
+  tree_forward_sum<T, G, 6>(c, cacc);
   for (int b = 1 + lane; b < m.nbody; b += G) {
     T in[10], cv[6], ca[6], f[6], t1[6], t2[6];
 #pragma unroll
@@ -1548,23 +1568,7 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
     for (int k = 0; k < 6; k++) cfrc[6 * b + k] = f[k] + t2[k];
   }
   gsync<G>();
-  for (int lev = m.nlevel - 1; lev >= 0; lev--) {
-    for (int idx = m.level_adr[lev] + lane; idx < m.level_adr[lev + 1]; idx += G) {
-      int b = m.level_body[idx];
-      if (m.child_adr[b] == m.child_adr[b + 1]) continue;
-      T s[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) s[k] = cfrc[6 * b + k];
-      for (int ci = m.child_adr[b]; ci < m.child_adr[b + 1]; ci++) {
-        int ch = m.child_id[ci];
-#pragma unroll
-        for (int k = 0; k < 6; k++) s[k] += cfrc[6 * ch + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) cfrc[6 * b + k] = s[k];
-    }
-    gsync<G>();
-  }
+  tree_backward_sum<T, G, 6>(c, cfrc, m.nround_inner);
   // fluid forces per body (inertia-box model) into bfrc = [torque; force] at xipos
   T* bfrc = w + L.bfrc;
   if (m.has_fluid) {

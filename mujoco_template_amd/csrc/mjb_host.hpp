@@ -48,7 +48,8 @@ struct HostModel {
   double timestep = 0, gravity[3] = {0, 0, 0}, density = 0, viscosity = 0, tolerance = 1e-8, meaninertia = 1;
   std::vector<std::pair<std::string, std::vector<double>>> fd;
   std::vector<std::pair<std::string, std::vector<int>>> id;
-  std::vector<int> level_adr, level_body, child_adr, child_id, tri_tab, dofact_adr, dofact_act, siteact, mpair;
+  std::vector<int> level_adr, level_body, child_adr, child_id, tri_tab, dofact_adr, dofact_act, siteact, mpair, body_round;
+  int nround = 0, nround_inner = 0;
   std::vector<unsigned long long> body_dofmask, dof_ancmask;
 
   const std::vector<double>& D(const char* k) const {
@@ -113,6 +114,22 @@ struct HostModel {
       for (int b = 1; b < nbody; b++) if (depth[b] == lev) level_body.push_back(b);
     }
     level_adr[nlevel] = (int)level_body.size();
+    // schedule of the subtree sums (tree_backward_sum): deepest level first, one sibling rank per round; the rounds of
+    // the depth-1 bodies (which add into the world body) come last
+    {
+      std::vector<int> rank(nbody, 0), nrank(maxd + 2, 0), base(maxd + 2, 0);
+      for (int b = 1; b < nbody; b++) {
+        int r = 0;
+        for (int o = 1; o < b; o++) if (parent[o] == parent[b]) r++;
+        rank[b] = r;
+        if (r + 1 > nrank[depth[b]]) nrank[depth[b]] = r + 1;
+      }
+      int acc = 0;
+      for (int lev = maxd; lev >= 1; lev--) { if (lev == 1) nround_inner = acc; base[lev] = acc; acc += nrank[lev]; }
+      nround = acc;
+      body_round.assign(nbody, -1);
+      for (int b = 1; b < nbody; b++) body_round[b] = base[depth[b]] + rank[b];
+    }
     child_adr.assign(nbody + 1, 0);
     child_id.clear();
     for (int b = 0; b < nbody; b++) {
@@ -187,7 +204,7 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
     return (FP)alloc.putf(tv);
   };
   auto Iq = [&](const char* k) -> IP { return (IP)alloc.puti(h.I(k)); };
-  m.body_parentid = Iq("body_parentid"); m.body_depth = Iq("body_depth"); m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
+  m.body_parentid = Iq("body_parentid"); m.body_depth = Iq("body_depth"); m.body_round = (IP)alloc.puti(h.body_round); m.nround = h.nround; m.nround_inner = h.nround_inner; m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
   m.body_dofadr = Iq("body_dofadr"); m.body_dofnum = Iq("body_dofnum");
   m.level_adr = (IP)alloc.puti(h.level_adr); m.level_body = (IP)alloc.puti(h.level_body); m.child_adr = (IP)alloc.puti(h.child_adr); m.child_id = (IP)alloc.puti(h.child_id); m.tri_tab = (IP)alloc.puti(h.tri_tab);
   m.dofact_adr = (IP)alloc.puti(h.dofact_adr); m.dofact_act = (IP)alloc.puti(h.dofact_act); m.siteact = (IP)alloc.puti(h.siteact); m.mpair = (IP)alloc.puti(h.mpair);

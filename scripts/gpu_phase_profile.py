@@ -13,10 +13,11 @@ n = 100
 sim.rollout(n, CTRL_RANDOM, seed=1, step0=50); sim.sync()
 p = sim.profile_get().astype(float) / (B * n)
 names = ["kinematics", "com_pos", "crb+factorM", "collision", "constraints", "vel/bias/passive", "actuation+Msolve", "solver(rest)", "integrate(euler)", "other", "solver:direction(H,chol,solve)", "solver:linesearch"]
-tot = p[:12].sum() + p[15]
+tot = p[:12].sum() + p[15] + p[20:24].sum()
 print(f"B={B}: cycles per env-step {tot:.0f}")
 for k, nm in enumerate(names):
     print(f"  {nm:34s} {p[k]:9.0f}  {100*p[k]/tot:5.1f}%")
 print(f"  {'solver:Mv,jv products':34s} {p[15]:9.0f}  {100*p[15]/tot:5.1f}%")
 print(f"  per env-step: line-search iterations {p[12]:.2f}, Newton directions {p[13]:.2f}, Hessian factorisations {p[14]:.2f}")
 print(f"  inside all factorisations (M, M+hD, H): {p[19]:.0f} cycles = load/assembly {p[16]:.0f} + panel loop {p[17]:.0f} + store/back-substitution {p[18]:.0f}")
+print(f"  sub-stamps (temporary instrumentation): [20] {p[20]:.0f}  [21] {p[21]:.0f}  [22] {p[22]:.0f}  [23] {p[23]:.0f}")
