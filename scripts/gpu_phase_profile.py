@@ -20,4 +20,5 @@ for k, nm in enumerate(names):
 print(f"  {'solver:Mv,jv products':34s} {p[15]:9.0f}  {100*p[15]/tot:5.1f}%")
 print(f"  per env-step: line-search iterations {p[12]:.2f}, Newton directions {p[13]:.2f}, Hessian factorisations {p[14]:.2f}")
 print(f"  inside all factorisations (M, M+hD, H): {p[19]:.0f} cycles = load/assembly {p[16]:.0f} + panel loop {p[17]:.0f} + store/back-substitution {p[18]:.0f}")
-print(f"  sub-stamps (temporary instrumentation): [20] {p[20]:.0f}  [21] {p[21]:.0f}  [22] {p[22]:.0f}  [23] {p[23]:.0f}")
+if p[20:24].sum() > 0:      # scratch slots for ad-hoc MJB_STAMP(c, 20..23) inside a phase
+    print(f"  sub-stamps: [20] {p[20]:.0f}  [21] {p[21]:.0f}  [22] {p[22]:.0f}  [23] {p[23]:.0f}")
