@@ -64,7 +64,7 @@ int mjb_sync(mjbData* d);
 int mjb_data_info(mjbData* d, int* batch, int* dtype, int* lanes, int* nconmax, int* nefcmax, int* lds_bytes_per_env);
 
 /* device pointer of a [batch, n] state array: qpos qvel ctrl qacc qacc_warmstart (dtype of the data),
- * time (float64 [batch]), xpos xquat xipos site_xpos geom_xpos subtree_com sensordata, counters (int32 [batch, 8]) */
+ * time (float64 [batch]), xpos xquat xipos site_xpos geom_xpos subtree_com sensordata qfrc_inverse actuator_moment, counters (int32 [batch, 8]) */
 int mjb_array_ptr(mjbData* d, const char* name, void** dev_ptr, long* per_env, int* dtype);
 /* host <-> device copies with conversion to/from float64 (state snapshot/restore, reference state_utils.py:9-31) */
 int mjb_get_array(mjbData* d, const char* name, double* host_out);
@@ -75,6 +75,10 @@ int mjb_get_counters(mjbData* d, int* host_out /* [batch, 8] */);
 int mjb_reset(mjbData* d, int key);
 /* mj_forward (reference model.py:53-54): fills qacc and the kinematic outputs */
 int mjb_forward(mjbData* d);
+/* mj_inverse (reference setpoints.py:29-31 steady_ctrl0, examples/humanoid/controllers/lqr.py:57-70): inverse dynamics at the
+ * current (qpos, qvel, qacc) of every environment -> array "qfrc_inverse" [batch, nv]; the same pass fills
+ * "actuator_moment" [batch, nu, nv] (dense form of data.actuator_moment, which setpoints.py:40-47 densifies).  State is not advanced. */
+int mjb_inverse(mjbData* d);
 /* nstep x mj_step (reference model.py:56-57, env.py:190), ctrl taken from data.ctrl */
 int mjb_step(mjbData* d, int nstep);
 /* fused rollout = the body of runtime.iterate_passive (reference runtime.py:631-663) for a device-side

@@ -68,6 +68,7 @@ def load_library() -> ctypes.CDLL:
     L.mjb_get_counters.argtypes = [vp, vp]
     L.mjb_reset.argtypes = [vp, ci]
     L.mjb_forward.argtypes = [vp]
+    L.mjb_inverse.argtypes = [vp]
     L.mjb_step.argtypes = [vp, ci]
     L.mjb_rollout.argtypes = [vp, ci, ci, cu, cu, cd, vp, vp, ci]
     L.mjb_set_feedback.argtypes = [vp, vp, vp, vp, vp]
@@ -84,7 +85,7 @@ def load_library() -> ctypes.CDLL:
     L.mjb_debug_get.argtypes = [vp, ctypes.c_char_p, vp, cl]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
-                 "mjb_forward", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
+                 "mjb_forward", "mjb_inverse", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get"):
         getattr(L, name).restype = ci
     _LIB = L
@@ -234,6 +235,10 @@ class BatchSim:
 
     def forward(self) -> None:
         _check(load_library().mjb_forward(self.ptr))
+
+    def inverse(self) -> None:
+        """mj_inverse on every environment: fills the arrays ``qfrc_inverse`` [B, nv] and ``actuator_moment`` [B, nu*nv]."""
+        _check(load_library().mjb_inverse(self.ptr))
 
     def step(self, nstep: int = 1) -> None:
         _check(load_library().mjb_step(self.ptr, int(nstep)))

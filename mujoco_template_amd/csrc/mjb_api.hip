@@ -107,6 +107,7 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   rc |= dev_alloc(d, &s.xpos, B * h.nbody * 3); rc |= dev_alloc(d, &s.xquat, B * h.nbody * 4); rc |= dev_alloc(d, &s.xipos, B * h.nbody * 3);
   rc |= dev_alloc(d, &s.site_xpos, B * h.nsite * 3); rc |= dev_alloc(d, &s.geom_xpos, B * h.ngeom * 3);
   rc |= dev_alloc(d, &s.subtree_com, B * h.nbody * 3); rc |= dev_alloc(d, &s.sensordata, B * h.nsensordata);
+  rc |= dev_alloc(d, &s.qfrc_inverse, B * h.nv); rc |= dev_alloc(d, &s.actuator_moment, B * h.nu * h.nv);
   rc |= dev_alloc(d, &s.counters, B * CNT_N);
   rc |= dev_alloc(d, &s.prof, (size_t)PH_N);
   if (rc) return -1;
@@ -116,6 +117,7 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   A["xpos"] = {s.xpos, h.nbody * 3L, 0}; A["xquat"] = {s.xquat, h.nbody * 4L, 0}; A["xipos"] = {s.xipos, h.nbody * 3L, 0};
   A["site_xpos"] = {s.site_xpos, h.nsite * 3L, 0}; A["geom_xpos"] = {s.geom_xpos, h.ngeom * 3L, 0};
   A["subtree_com"] = {s.subtree_com, h.nbody * 3L, 0}; A["sensordata"] = {s.sensordata, h.nsensordata, 0};
+  A["qfrc_inverse"] = {s.qfrc_inverse, h.nv, 0}; A["actuator_moment"] = {s.actuator_moment, (long)h.nu * h.nv, 0};
   A["counters"] = {s.counters, CNT_N, 2};
   return 0;
 }
@@ -382,6 +384,13 @@ int mjb_forward(mjbData* d) {
   HIPCHK(hipSetDevice(d->device));
   ObsSpecDev none; std::memset(&none, 0, sizeof(none));
   return launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, false);
+}
+
+int mjb_inverse(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  HIPCHK(hipSetDevice(d->device));
+  ObsSpecDev none; std::memset(&none, 0, sizeof(none));
+  return launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 2), none, nullptr, false);
 }
 
 int mjb_step(mjbData* d, int nstep) {

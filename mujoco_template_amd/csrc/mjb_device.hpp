@@ -453,6 +453,7 @@ template <typename T> using ModelRef = const DevModel<T> MJB_CONST&;
 typedef const Lay MJB_CONST& LayRef;
 
 template <typename T> struct Ctx {
+  bool skip_dynamics = false;   // inverse-dynamics mode: forward() stops before actuation / constraint solve
   const DevModel<T> MJB_CONST* mp;
   const Lay MJB_CONST* lp;
   T* w;      // T region of this environment's LDS slice
@@ -1899,6 +1900,7 @@ template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
   crb_factor<T, G>(c); MJB_STAMP(c, PH_CRB);
   make_constraint<T, G>(c); MJB_STAMP(c, PH_CONS);
   vel_bias_passive<T, G>(c); MJB_STAMP(c, PH_VEL);
+  if (c.skip_dynamics) return;                              // mj_inverse: position + velocity stages only (inverse_dynamics() follows)
   actuation_acceleration<T, G>(c); MJB_STAMP(c, PH_ACT);
   solve_constraints<T, G>(c); MJB_STAMP(c, PH_SOLVE);
   if (c.mp->nsensor > 0) { sensors<T, T, G>(c, c.w + c.lp->sens); gsync<G>(); }   // like mj_forward: sensors see the pre-integration state
@@ -2015,6 +2017,49 @@ template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, const StepArg
   gsync<G>();
 }
 
+// mj_inverse after forward() with skip_dynamics (reference setpoints.py:29-31): the constraint force follows in closed
+// form from jar = J qacc - aref (one-sided quadratic rows: force = -D jar where jar < 0), then
+// qfrc_inverse = M qacc + qfrc_bias - qfrc_passive - J^T force.  Also writes the dense actuator moment [nu, nv]
+// (joint transmission: gear at the joint's dof; site transmission: gear wrench in the site frame through the site Jacobian).
+template <typename T, typename TS, int G> MJB_DEV void inverse_dynamics(Ctx<T>& c, TS* inv_out, TS* moment_out) {
+  MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
+  T *J = w + L.efc_J, *aref = w + L.efc_aref, *D = w + L.efc_D, *force = w + L.efc_force, *qacc = w + L.qacc, *M = w + L.M;
+  T *qb = w + L.qfrc_bias, *qp = w + L.qfrc_passive, *qc = w + L.qfrc_constraint;
+  for (int r = lane; r < nefc; r += G) {
+    T jar = dot_lds(J + r * nv, 1, VecLds<T>{qacc}, nv) - aref[r];
+    force[r] = jar < 0 ? -D[r] * jar : (T)0;
+  }
+  gsync<G>();
+  for (int i = lane; i < nv; i += G) {
+    T fc = dot_lds(J + i, nv, VecLds<T>{force}, nefc);
+    T ma = dot_lds(M + i * nv, 1, VecLds<T>{qacc}, nv);
+    qc[i] = fc;
+    inv_out[i] = (TS)(ma + qb[i] - qp[i] - fc);
+  }
+  T *sx = w + L.site_xpos, *sm = w + L.site_xmat;
+  for (int idx = lane; idx < m.nu * nv; idx += G) {
+    int a = idx / nv, i = idx - a * nv, id = m.actuator_trnid[2 * a];
+    T v = 0;
+    if (m.actuator_trntype[a] == TRN_JOINT) v = (i == m.jnt_dofadr[id]) ? m.actuator_gear[6 * a] : (T)0;
+    else {
+      int b = m.site_bodyid[id];
+      if ((m.body_dofmask[b] >> i) & 1ull) {
+        T g[6], R[9], f[3], tq[3], pt[3] = {sx[3 * id], sx[3 * id + 1], sx[3 * id + 2]}, jp[3], jr[3];
+#pragma unroll
+        for (int q = 0; q < 6; q++) g[q] = m.actuator_gear[6 * a + q];
+#pragma unroll
+        for (int q = 0; q < 9; q++) R[q] = sm[9 * id + q];
+        mulmatvec3(f, R, g);
+        mulmatvec3(tq, R, g + 3);
+        jac_col<T>(c, b, i, pt, jp, jr);
+        v = dot3(jp, f) + dot3(jr, tq);
+      }
+    }
+    moment_out[idx] = (TS)v;
+  }
+  gsync<G>();
+}
+
 // A13 bad-state guard
 template <typename T, int G> MJB_DEV bool group_bad(const T* x, int n, int lane) {
   int bad = 0;
@@ -2072,7 +2117,8 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   c.pt = __builtin_amdgcn_s_memtime();
 #endif
-  const int nstep = a.mode == 1 ? 1 : a.nstep;
+  const int nstep = a.mode != 0 ? 1 : a.nstep;
+  c.skip_dynamics = a.mode == 2;
   const int nstage = (a.mode == 0 && m.integrator == INT_RK4) ? 4 : 1;
   for (int s = 0; s < nstep; s++) {
     if (a.mode == 0) {
@@ -2086,14 +2132,15 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     bool retried = false;
     for (int st = 0; st < nstage; st++) {
       forward<T, G>(c);                                   // the only call site of the forward pipeline
-      if (a.mode == 1) break;
+      if (a.mode != 0) break;
       if (st == 0 && !retried && group_bad<T, G>(w + L.qacc, nv, lane)) {
         badqacc++; reset_state<T, G>(c); time = 0; retried = true; st = -1;
         continue;
       }
       if (nstage == 4) rk4_stage<T, G>(c, st);
     }
-    if (a.mode == 1) break;
+    if (a.mode == 2) inverse_dynamics<T, TS, G>(c, d.qfrc_inverse + (size_t)env * nv, d.actuator_moment + (size_t)env * nu * nv);
+    if (a.mode != 0) break;
     if (nstage == 1) euler<T, G>(c);
     MJB_STAMP(c, PH_INTEG);
     time += a.dt;

@@ -97,6 +97,7 @@ struct DevData {
   TS *qpos, *qvel, *ctrl, *qacc, *qacc_warmstart;
   double* time;
   TS *xpos, *xquat, *xipos, *site_xpos, *geom_xpos, *subtree_com, *sensordata;
+  TS *qfrc_inverse, *actuator_moment;   // outputs of the inverse-dynamics mode: [batch, nv], [batch, nu, nv]
   int* counters;
   unsigned long long* prof;   // per-phase cycle sums (diagnostic -DMJB_PROFILE build only; null otherwise)
 };
@@ -123,7 +124,7 @@ struct StepArgs {
   unsigned seed, step0, env0;   // env0 = global index of this shard's first env (RNG is shard-invariant)
   double ctrl_scale;     // random-ctrl amplitude as a fraction of the ctrl half-range
   double dt;             // model timestep in float64 (time is accumulated in double whatever the state dtype)
-  int mode;              // 0 = step, 1 = forward only
+  int mode;              // 0 = step, 1 = forward only, 2 = inverse dynamics (mj_inverse) + dense actuator moment
   int write_kin;         // write xpos/xipos/site_xpos/geom_xpos/subtree_com/sensordata of the last forward pass
   int obs_every;         // >0: write flat obs every k steps into obs_out[(step/k), env, dim]
   // CTRL_FEEDBACK: ctrl = clip(u0 - K [differentiatePos(q0, qpos); qvel - v0]) with K [nu, 2nv] row-major (dtype of the arithmetic)

@@ -147,7 +147,8 @@ class MjModel:
 # ----------------------------------------------------------------------------------
 
 _STATE = ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart")       # writable, pushed when edited
-_DERIVED = ("xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "subtree_com", "sensordata")  # read-only outputs
+_DERIVED = ("xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "subtree_com", "sensordata",
+            "qfrc_inverse", "actuator_moment")  # read-only outputs (the last two: filled by mj_inverse)
 _SHAPE3 = {"xpos": 3, "xquat": 4, "xipos": 3, "site_xpos": 3, "geom_xpos": 3, "subtree_com": 3}
 
 
@@ -170,7 +171,9 @@ class MjData:
         c = model._c
         for name in _STATE + _DERIVED:
             _, n, _ = self._sim.array_ptr(name)
-            if name in _SHAPE3:
+            if name == "actuator_moment":
+                shape = (self.batch, model.nu, model.nv)        # dense; MuJoCo's CSR triplet is derived in the properties below
+            elif name in _SHAPE3:
                 shape = (self.batch, n // _SHAPE3[name], _SHAPE3[name])
             else:
                 shape = (self.batch, n)
@@ -238,6 +241,27 @@ class MjData:
         self._time[...] = value
         self._sim.set("time", self._time.reshape(self.batch, 1))
 
+    # data.actuator_moment is CSR in MuJoCo >= 3.1 (moment_rownnz / moment_rowadr / moment_colind); the reference densifies it
+    # with mju_sparse2dense (mujoco_template/setpoints.py:40-47).  The engine keeps it dense [nu, nv]; these views present
+    # the dense rows as CSR rows of full length so that the reference's densification code runs unchanged.
+    @property
+    def moment_rownnz(self) -> np.ndarray:
+        nu, nv = self.model.nu, self.model.nv
+        r = np.full(nu, nv, dtype=np.int32)
+        return r if self.batch == 1 else np.tile(r, (self.batch, 1))
+
+    @property
+    def moment_rowadr(self) -> np.ndarray:
+        nu, nv = self.model.nu, self.model.nv
+        r = (np.arange(nu, dtype=np.int32) * nv)
+        return r if self.batch == 1 else np.tile(r, (self.batch, 1))
+
+    @property
+    def moment_colind(self) -> np.ndarray:
+        nu, nv = self.model.nu, self.model.nv
+        r = np.tile(np.arange(nv, dtype=np.int32), nu)
+        return r if self.batch == 1 else np.tile(r, (self.batch, 1))
+
     def counters(self) -> dict[str, np.ndarray]:
         """Per-environment diagnostics: ncon, nefc, solver_niter, dropped contacts/rows, bad-state resets."""
         return self._sim.counters()
@@ -269,6 +293,25 @@ def mj_forward(model: MjModel, data: MjData) -> None:
     data.push_host_edits()
     data._sim.forward()
     data.mark_device_newer(eager=True)
+
+
+def mj_inverse(model: MjModel, data: MjData) -> None:
+    """Inverse dynamics at the current (qpos, qvel, qacc): fills ``data.qfrc_inverse`` and ``data.actuator_moment``
+    (reference call sites: ``mujoco_template/setpoints.py:29-31``, ``examples/humanoid/controllers/lqr.py:57-70``)."""
+    _check(model, data)
+    data.push_host_edits()
+    data._sim.inverse()
+    data._dev_newer |= {"qfrc_inverse", "actuator_moment"} | set(_DERIVED)
+
+
+def mju_sparse2dense(res: np.ndarray, mat: np.ndarray, rownnz: np.ndarray, rowadr: np.ndarray, colind: np.ndarray) -> None:
+    """CSR -> dense, in place on ``res`` [nr, nc] (the slice of ``mujoco.mju_sparse2dense`` the reference uses)."""
+    res[...] = 0.0
+    mat = np.asarray(mat).reshape(-1)
+    colind = np.asarray(colind).reshape(-1)
+    for r in range(res.shape[0]):
+        a, n = int(rowadr[r]), int(rownnz[r])
+        res[r, colind[a:a + n]] = mat[a:a + n]
 
 
 def mj_step(model: MjModel, data: MjData, nstep: int = 1) -> None:
@@ -385,6 +428,6 @@ def mj_differentiatePos(model: MjModel, qvel: np.ndarray, dt: float, qpos1: np.n
 
 __all__ = [
     "MjModel", "MjData", "mjtObj", "mjtJoint", "FatalError", "mj_name2id", "mj_id2name", "mj_forward", "mj_step",
-    "mj_resetData", "mj_resetDataKeyframe", "mj_subtreeCoM", "mjd_transitionFD", "mj_jacSite", "mj_jacBody",
+    "mj_inverse", "mju_sparse2dense", "mj_resetData", "mj_resetDataKeyframe", "mj_subtreeCoM", "mjd_transitionFD", "mj_jacSite", "mj_jacBody",
     "mj_jacBodyCom", "mj_jacSubtreeCom", "mj_integratePos", "mj_differentiatePos",
 ]

@@ -71,7 +71,7 @@ struct mjoData {
   const mjoModel* m;
   double time;
   double *qpos, *qvel, *ctrl, *qacc, *qacc_warmstart, *qacc_smooth, *qfrc_applied;
-  double *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qfrc_constraint;
+  double *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qfrc_constraint, *qfrc_inverse;
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
   double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc;
   double *qM, *qL, *qH;             /* dense nv*nv: mass matrix, its Cholesky factor, solver Hessian factor */
@@ -362,7 +362,7 @@ mjoData* mjo_data_create(const mjoModel* m) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nb = m->nbody, nj = m->njnt, ng = m->ngeom, ns = m->nsite, nt = m->ntendon;
   d->qpos = dalloc(nq); d->qvel = dalloc(nv); d->ctrl = dalloc(nu); d->qacc = dalloc(nv); d->qacc_warmstart = dalloc(nv);
   d->qacc_smooth = dalloc(nv); d->qfrc_applied = dalloc(nv); d->qfrc_bias = dalloc(nv); d->qfrc_passive = dalloc(nv);
-  d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv);
+  d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv); d->qfrc_inverse = dalloc(nv);
   d->xpos = dalloc(nb * 3); d->xquat = dalloc(nb * 4); d->xmat = dalloc(nb * 9); d->xipos = dalloc(nb * 3); d->ximat = dalloc(nb * 9);
   d->xanchor = dalloc(nj * 3); d->xaxis = dalloc(nj * 3); d->geom_xpos = dalloc(ng * 3); d->geom_xmat = dalloc(ng * 9);
   d->site_xpos = dalloc(ns * 3); d->site_xmat = dalloc(ns * 9); d->subtree_com = dalloc(nb * 3);
@@ -387,7 +387,7 @@ mjoData* mjo_data_create(const mjoModel* m) {
 void mjo_data_free(mjoData* d) {
   if (!d) return;
   double** f[] = {&d->qpos, &d->qvel, &d->ctrl, &d->qacc, &d->qacc_warmstart, &d->qacc_smooth, &d->qfrc_applied, &d->qfrc_bias,
-    &d->qfrc_passive, &d->qfrc_actuator, &d->qfrc_smooth, &d->qfrc_constraint, &d->xpos, &d->xquat, &d->xmat, &d->xipos, &d->ximat,
+    &d->qfrc_passive, &d->qfrc_actuator, &d->qfrc_smooth, &d->qfrc_constraint, &d->qfrc_inverse, &d->xpos, &d->xquat, &d->xmat, &d->xipos, &d->ximat,
     &d->xanchor, &d->xaxis, &d->geom_xpos, &d->geom_xmat, &d->site_xpos, &d->site_xmat, &d->subtree_com, &d->cinert, &d->crb,
     &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->qM, &d->qL, &d->qH, &d->ten_length, &d->ten_J, &d->ten_velocity,
     &d->actuator_length, &d->actuator_velocity, &d->actuator_force, &d->actuator_moment, &d->sensordata, &d->efc_J, &d->efc_pos,
@@ -403,7 +403,7 @@ double* mjo_data_array(mjoData* d, const char* name, long* count) {
   int nv = m->nv, nb = m->nbody;
 #define F(f, c) if (!strcmp(name, #f)) { if (count) *count = (long)(c); return d->f; }
   F(qpos, m->nq) F(qvel, nv) F(ctrl, m->nu) F(qacc, nv) F(qacc_warmstart, nv) F(qacc_smooth, nv) F(qfrc_applied, nv)
-  F(qfrc_bias, nv) F(qfrc_passive, nv) F(qfrc_actuator, nv) F(qfrc_smooth, nv) F(qfrc_constraint, nv)
+  F(qfrc_bias, nv) F(qfrc_passive, nv) F(qfrc_actuator, nv) F(qfrc_smooth, nv) F(qfrc_constraint, nv) F(qfrc_inverse, nv)
   F(xpos, nb * 3) F(xquat, nb * 4) F(xmat, nb * 9) F(xipos, nb * 3) F(ximat, nb * 9) F(xanchor, m->njnt * 3) F(xaxis, m->njnt * 3)
   F(geom_xpos, m->ngeom * 3) F(geom_xmat, m->ngeom * 9) F(site_xpos, m->nsite * 3) F(site_xmat, m->nsite * 9) F(subtree_com, nb * 3)
   F(cinert, nb * 10) F(crb, nb * 10) F(cdof, nv * 6) F(cdof_dot, nv * 6) F(cvel, nb * 6) F(cacc, nb * 6) F(cfrc, nb * 6)
@@ -1230,6 +1230,35 @@ void mjo_forward(const mjoModel* m, mjoData* d) {
   acceleration(m, d);
   solve_constraints(m, d);
   sensors(m, d);
+}
+
+/* mj_inverse [MJ-KNOWLEDGE engine_inverse.c]: inverse dynamics at the current (qpos, qvel, qacc), continuous-time form
+ * (mjENBL_INVDISCRETE off).  Position and velocity stages as in mj_forward; the constraint force follows in closed form
+ * from jar = J qacc - aref (mj_invConstraint -> mj_constraintUpdate: one-sided quadratic rows, force = -D jar where
+ * jar < 0); qfrc_inverse = M qacc + qfrc_bias - qfrc_passive - qfrc_constraint.
+ * Reference call sites: mujoco_template/setpoints.py:29-31, examples/humanoid/controllers/lqr.py:57-70. */
+void mjo_inverse(const mjoModel* m, mjoData* d) {
+  int nv = m->nv;
+  kinematics(m, d);
+  com_pos(m, d);
+  tendon_transmission(m, d);
+  crb_factor(m, d);
+  collision(m, d);
+  make_constraint(m, d);
+  com_vel(m, d);
+  passive(m, d);
+  reference_constraint(m, d);
+  rne_bias(m, d);
+  mul_J(m, d, d->efc_jar, d->qacc);
+  for (int i = 0; i < d->nefc; i++) d->efc_jar[i] -= d->efc_aref[i];
+  constraint_update(m, d, d->efc_jar, NULL);
+  for (int k = 0; k < nv; k++) {
+    double s = 0;
+    for (int i = 0; i < d->nefc; i++) s += d->efc_J[(size_t)i * nv + k] * d->efc_force[i];
+    d->qfrc_constraint[k] = s;
+  }
+  mul_M(m, d, d->s_Ma, d->qacc);
+  for (int k = 0; k < nv; k++) d->qfrc_inverse[k] = d->s_Ma[k] + d->qfrc_bias[k] - d->qfrc_passive[k] - d->qfrc_constraint[k];
 }
 
 /* A16 mj_integratePos / mj_differentiatePos */

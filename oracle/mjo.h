@@ -53,6 +53,8 @@ void mjo_set_time(mjoData* d, double t);
 void mjo_reset(const mjoModel* m, mjoData* d);
 int mjo_reset_keyframe(const mjoModel* m, mjoData* d, int key);
 void mjo_forward(const mjoModel* m, mjoData* d);
+/* mj_inverse: fills qfrc_inverse from (qpos, qvel, qacc); reference mujoco_template/setpoints.py:29-31 */
+void mjo_inverse(const mjoModel* m, mjoData* d);
 void mjo_step(const mjoModel* m, mjoData* d);
 
 /* random-ctrl rollout used by the CPU baseline / parity tests:

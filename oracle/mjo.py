@@ -54,6 +54,7 @@ def lib() -> ctypes.CDLL:
         L.mjo_reset_keyframe.restype = ci
         L.mjo_reset_keyframe.argtypes = [vp, vp, ci]
         L.mjo_forward.argtypes = [vp, vp]
+        L.mjo_inverse.argtypes = [vp, vp]
         L.mjo_step.argtypes = [vp, vp]
         L.mjo_random_ctrl.argtypes = [vp, vp, cu, cu, cu, cd]
         L.mjo_rollout_random.argtypes = [vp, vp, ci, cu, cu, cu, cd]
@@ -114,7 +115,7 @@ class OracleData:
     """One float64 environment.  Array attributes are live numpy views."""
 
     _FIELDS = ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "qacc_smooth", "qfrc_applied", "qfrc_bias",
-               "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qfrc_constraint", "xpos", "xquat", "xmat", "xipos",
+               "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qfrc_constraint", "qfrc_inverse", "xpos", "xquat", "xmat", "xipos",
                "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "site_xpos", "site_xmat", "subtree_com",
                "cinert", "crb", "cdof", "cdof_dot", "cvel", "cacc", "cfrc", "qM", "qL", "ten_length", "ten_J",
                "actuator_length", "actuator_velocity", "actuator_force", "actuator_moment", "sensordata")
@@ -181,6 +182,10 @@ class OracleData:
 
     def forward(self) -> None:
         lib().mjo_forward(self.model.ptr, self.ptr)
+
+    def inverse(self) -> None:
+        """mj_inverse: qfrc_inverse from the current (qpos, qvel, qacc)."""
+        lib().mjo_inverse(self.model.ptr, self.ptr)
 
     def step(self, n: int = 1) -> None:
         for _ in range(n):

@@ -52,6 +52,7 @@ class EmuEnv:
             "xpos": np.zeros(3 * m.nbody), "xquat": np.zeros(4 * m.nbody), "xipos": np.zeros(3 * m.nbody),
             "site_xpos": np.zeros(max(3 * m.nsite, 1)), "geom_xpos": np.zeros(max(3 * m.ngeom, 1)), "subtree_com": np.zeros(3 * m.nbody),
             "sensordata": np.zeros(max(m.nsensordata, 1)),
+            "qfrc_inverse": np.zeros(nv), "actuator_moment": np.zeros(max(m.nu, 1) * nv),
             "qM": np.zeros(nv * nv), "qfrc_bias": np.zeros(nv), "qfrc_passive": np.zeros(nv), "qfrc_actuator": np.zeros(nv),
             "qacc_smooth": np.zeros(nv), "qfrc_constraint": np.zeros(nv),
             "efc_J": np.zeros(self.nefc_max * nv), "efc_aref": np.zeros(self.nefc_max), "efc_D": np.zeros(self.nefc_max),
@@ -77,6 +78,9 @@ class EmuEnv:
                               ctypes.c_float(scale), ctypes.c_int(mode))
         if rc != 0:
             raise RuntimeError(lib().mjbemu_last_error().decode())
+
+    def inverse(self) -> None:
+        self.run(1, mode=2)
 
     def forward(self) -> None:
         self.run(mode=1)

@@ -80,6 +80,8 @@ int mjbemu_run(int nfield, const char* const* names, const void* const* ptrs, co
   d.qacc_warmstart = (double*)io("qacc_warmstart"); d.time = (double*)io("time"); d.counters = (int*)io("counters");
   d.xpos = (double*)io("xpos"); d.xquat = (double*)io("xquat"); d.xipos = (double*)io("xipos"); d.site_xpos = (double*)io("site_xpos");
   d.geom_xpos = (double*)io("geom_xpos"); d.subtree_com = (double*)io("subtree_com"); d.sensordata = (double*)io("sensordata");
+  d.qfrc_inverse = (double*)io("qfrc_inverse"); d.actuator_moment = (double*)io("actuator_moment");
+  if (mode == 2 && (!d.qfrc_inverse || !d.actuator_moment)) { g_err = "inverse mode needs qfrc_inverse and actuator_moment"; return -1; }
   if (!d.qpos || !d.qvel || !d.ctrl || !d.qacc || !d.qacc_warmstart || !d.time || !d.counters) { g_err = "missing state arrays"; return -1; }
   DevDebug<double> dbg;
   std::memset(&dbg, 0, sizeof(dbg));

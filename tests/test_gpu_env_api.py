@@ -328,3 +328,31 @@ def test_linear_feedback_controller_fused_equals_host_loop():
         b.step(return_obs=False)
     assert np.abs(np.array(a.data.qpos) - np.array(b.data.qpos)).max() < 1e-9
     assert np.abs(np.array(a.data.ctrl) - np.array(b.data.ctrl)).max() < 1e-9
+
+
+def test_steady_ctrl0_drone_hover_and_errors():
+    """reference setpoints.steady_ctrl0 (setpoints.py:10-58): the drone's hover keyframe needs ctrl 3.2495625 per rotor
+    (x2.xml:90: 1.325 kg * 9.81 / 4); argument checks and the nu == 0 error keep the reference's exception types."""
+    h = mt.ModelHandle.from_xml_path(MODELS["drone2"], dtype="float64")
+    m, d = h.model, h.data
+    key_qpos = np.array(m.compiled.arrays["key_qpos"]).reshape(-1, m.nq)[0]
+    before = (np.array(d.qpos), np.array(d.qvel), float(d.time))
+    u = mt.steady_ctrl0(m, d, key_qpos)
+    assert u.shape == (m.nu,) and u == pytest.approx([3.2495625] * 4, abs=1e-8)
+    assert np.array_equal(np.array(d.qpos), before[0]) and np.array_equal(np.array(d.qvel), before[1]) and float(d.time) == before[2]
+    with pytest.raises(mt.ConfigError):
+        mt.steady_ctrl0(m, d, np.zeros(m.nq + 1))
+    with pytest.raises(mt.ConfigError):
+        mt.steady_ctrl0(m, d, key_qpos, np.zeros(m.nv + 2))
+    # the reference's own densification code path runs unchanged against the CSR views
+    mj.mj_resetDataKeyframe(m, d, 0); mj.mj_forward(m, d); d.qacc[:] = 0.0; mj.mj_inverse(m, d)
+    M = np.zeros((m.nu, m.nv))
+    mj.mju_sparse2dense(M, np.reshape(d.actuator_moment, (-1,)), d.moment_rownnz, d.moment_rowadr, np.reshape(d.moment_colind, (-1,)))
+    assert (np.atleast_2d(np.array(d.qfrc_inverse)) @ np.linalg.pinv(M)).ravel() == pytest.approx([3.2495625] * 4, abs=1e-8)
+    # batched, fp32: one set-point for all environments -> [batch, nu]
+    hb = mt.ModelHandle.from_xml_path(MODELS["drone2"], batch=3)
+    ub = mt.steady_ctrl0(hb.model, hb.data, key_qpos)
+    assert ub.shape == (3, m.nu) and np.abs(ub - 3.2495625).max() < 1e-4
+    nu0 = mt.ModelHandle.from_xml_string("<mujoco><worldbody><body><joint type='hinge'/><geom size='0.1'/></body></worldbody></mujoco>")
+    with pytest.raises(mt.CompatibilityError):
+        mt.steady_ctrl0(nu0.model, nu0.data, np.zeros(1))

@@ -382,3 +382,29 @@ def test_device_feedback_controller_matches_host_law(world):
             assert np.abs(sim.get("ctrl") - np.stack([od.ctrl for od in ods])).max() <= (1e-8 if dtype == "float64" else 5e-3)
     with pytest.raises(mt.ConfigError):
         BatchSim(world("cartpole")[2], 2).rollout(1, 3)          # feedback mode without gains
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("humanoid", "float64", 1e-9), ("humanoid", "float32", 2e-3), ("drone2", "float64", 1e-10)])
+def test_inverse_dynamics_matches_oracle(world, name, dtype, tol):
+    """mjb_inverse (reference setpoints.py:29-31) on states with contacts, random qacc: qfrc_inverse and the dense
+    actuator moment vs the oracle.  fp32 tolerance: relative to the largest generalized force (M qacc cancels bias)."""
+    cm, om, dm = world(name)
+    B = 6
+    sim = BatchSim(dm, B, dtype=dtype)
+    rng = np.random.default_rng(7)
+    ods = []
+    q = np.zeros((B, cm.nq)); v = np.zeros((B, cm.nv)); a = rng.normal(size=(B, cm.nv))
+    for e in range(B):
+        od = mjo.OracleData(om)
+        od.rollout_random(60 + 20 * e, seed=11, env=e, scale=SCALE[name])
+        od.qacc[:] = a[e]
+        q[e], v[e] = od.qpos, od.qvel
+        od.inverse(); ods.append(od)
+    sim.set("qpos", q); sim.set("qvel", v); sim.set("qacc", a)
+    sim.inverse()
+    got = sim.get("qfrc_inverse"); mom = sim.get("actuator_moment")
+    for e in range(B):
+        ref = ods[e].qfrc_inverse
+        assert np.abs(got[e] - ref).max() <= tol * max(1.0, np.abs(ref).max()), e
+        assert np.abs(mom[e] - ods[e].actuator_moment).max() <= (1e-12 if dtype == "float64" else 1e-5)
+    assert np.array_equal(sim.get("qacc"), a if dtype == "float64" else a.astype(np.float32).astype(np.float64))

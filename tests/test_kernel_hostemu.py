@@ -104,3 +104,18 @@ def test_drone_sensors_match_oracle(compiled):
     assert np.abs(e.sensordata[:10] - od.sensordata).max() < 1e-11
     od.step(); e.step()                        # sensordata keeps the values of the forward pass inside the step
     assert np.abs(e.sensordata[:10] - od.sensordata).max() < 1e-11
+
+
+@pytest.mark.parametrize("name,G", [("drone2", 16), ("humanoid", 64), ("cartpole", 8)])
+def test_inverse_dynamics_matches_oracle(compiled, name, G):
+    """mjb_inverse's device code (mode 2) vs the oracle's mj_inverse restatement, state with contacts / limits."""
+    cm, od, e = _pair(compiled, name, G)
+    od.rollout_random(40, seed=3, env=1, scale=0.3 if name != "cartpole" else 0.01)
+    rng = np.random.default_rng(1)
+    od.qacc[:] = rng.normal(size=cm.nv)
+    e.qpos[:] = od.qpos; e.qvel[:] = od.qvel; e.qacc[:] = od.qacc
+    od.inverse(); e.inverse()
+    s = max(1.0, np.abs(od.qfrc_inverse).max())
+    assert np.abs(e.qfrc_inverse - od.qfrc_inverse).max() < 1e-10 * s
+    assert np.abs(e.actuator_moment[: cm.nu * cm.nv] - od.actuator_moment).max() < 1e-12
+    assert np.abs(e.qacc - od.qacc).max() == 0            # state untouched

