@@ -21,7 +21,8 @@ from .jacobians import compute_requested_jacobians
 from .linearization import linearize_discrete
 from .model import ModelHandle
 from .observations import ObservationExtractor, ObservationProducer, ObservationSpec
-from .runtime import StepHook, iterate_passive, run_passive_headless
+from .logging import DataProbe, StateControlRecorder
+from .runtime import StepHook, TrajectoryLogger, iterate_passive, run_passive_headless
 from .setpoints import steady_ctrl0
 
 __version__ = "0.1.0"
@@ -31,6 +32,7 @@ __all__ = [
     "ControlSpace", "Controller", "ControllerCapabilities", "ObservationSpec", "ObservationExtractor",
     "ObservationProducer", "ModelHandle", "CompatibilityReport", "StepResult", "Env", "ZeroController",
     "PositionTargetDemo", "RandomCtrlController", "LinearFeedbackController", "check_controller_compat", "linearize_discrete",
-    "compute_requested_jacobians", "StepHook", "iterate_passive", "run_passive_headless", "steady_ctrl0", "ObservationDict",
+    "compute_requested_jacobians", "StepHook", "iterate_passive", "run_passive_headless", "steady_ctrl0", "DataProbe",
+    "StateControlRecorder", "TrajectoryLogger", "ObservationDict",
     "ObservationArray", "Observation", "JacobianDict", "JacobiansDict", "InfoDict", "StateSnapshot", "__version__",
 ]

@@ -140,11 +140,12 @@ class Env:
         extras = bool(self.extractor.extra_items) if self.extractor is not None else False
         return self._device_mode() is not None and not any((self.reward_fn, self.done_fn, self.info_fn)) and not extras
 
-    def rollout(self, nsteps: int, *, obs_every: int = 0, obs_out=None):
+    def rollout(self, nsteps: int, *, obs_every: int = 0, obs_out=None, obs_spec_handle=None):
         """Advance ``nsteps`` in ONE kernel launch (controller evaluated on the device).
 
         With ``obs_every = k > 0`` the flat observation of every k-th step is written on the GPU
-        and returned as a torch tensor ``[nsteps // k, batch, obs_dim]``.
+        and returned as a torch tensor ``[nsteps // k, batch, obs_dim]``.  ``obs_spec_handle`` (a device
+        ``ObsSpecHandle``) replaces the environment's own observation layout for this call (the CSV recorder's feed).
         """
         mode = self._device_mode()
         if mode is None:
@@ -162,8 +163,7 @@ class Env:
         if obs_every > 0:
             import torch
 
-            ex = self._ensure_extractor()
-            spec = ex.device_spec(data)
+            spec = obs_spec_handle if obs_spec_handle is not None else self._ensure_extractor().device_spec(data)
             if obs_out is None:
                 obs_out = torch.empty((nsteps // obs_every, data.batch, spec.dim), device=f"cuda:{sim.device}",
                                       dtype=torch.float32 if sim.dtype == "float32" else torch.float64)

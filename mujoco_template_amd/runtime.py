@@ -7,8 +7,10 @@ whole batch instead of one per step per environment).
 
 from __future__ import annotations
 
-from collections.abc import Callable, Iterable, Iterator
-from typing import TYPE_CHECKING
+import csv
+from collections.abc import Callable, Iterable, Iterator, Sequence
+from pathlib import Path
+from typing import IO, TYPE_CHECKING, Any
 
 import numpy as np
 
@@ -88,3 +90,57 @@ def run_passive_headless(env: "Env", *, duration: float | None = None, max_steps
 
 
 __all__ = ["StepHook", "iterate_passive", "run_passive_headless", "_normalize_hooks"]
+
+
+class TrajectoryLogger:
+    """Row sink with a fixed header, optionally backed by a CSV file (reference ``runtime.py:559-617``).
+
+    ``path=None`` keeps the formatting / length check but writes nothing.  Usable as a context manager; the file
+    is opened (parents created) on ``__enter__`` and the header row is written first.
+    """
+
+    def __init__(self, path: str | Path | None, columns: Sequence[str], formatter: Callable[["StepResult"], Sequence[Any]]) -> None:
+        if not columns:
+            raise ConfigError("TrajectoryLogger requires at least one column name.")
+        if formatter is None:
+            raise ConfigError("TrajectoryLogger requires a formatter callable.")
+        self._path = None if path is None else Path(path)
+        self._columns = tuple(columns)
+        self._formatter = formatter
+        self._file: IO[str] | None = None
+        self._writer = None
+
+    @property
+    def columns(self) -> tuple[str, ...]:
+        return self._columns
+
+    @property
+    def enabled(self) -> bool:
+        return self._path is not None
+
+    def __enter__(self) -> "TrajectoryLogger":
+        if self._path is not None and self._file is None:
+            self._path.parent.mkdir(parents=True, exist_ok=True)
+            self._file = self._path.open("w", newline="", encoding="utf-8")
+            self._writer = csv.writer(self._file)
+            self._writer.writerow(self._columns)
+        return self
+
+    def __exit__(self, exc_type, exc, exc_tb) -> None:
+        self.close()
+
+    def close(self) -> None:
+        if self._file is not None:
+            self._file.close()
+        self._file = self._writer = None
+
+    def write_row(self, row: Sequence[Any]) -> tuple[Any, ...]:
+        row = tuple(row)
+        if len(row) != len(self._columns):
+            raise ConfigError(f"Formatter returned a row of unexpected length ({len(row)} received, expected {len(self._columns)}).")
+        if self._writer is not None:
+            self._writer.writerow(row)
+        return row
+
+    def log(self, result: "StepResult") -> tuple[Any, ...]:
+        return self.write_row(self._formatter(result))

@@ -356,3 +356,56 @@ def test_steady_ctrl0_drone_hover_and_errors():
     nu0 = mt.ModelHandle.from_xml_string("<mujoco><worldbody><body><joint type='hinge'/><geom size='0.1'/></body></worldbody></mujoco>")
     with pytest.raises(mt.CompatibilityError):
         mt.steady_ctrl0(nu0.model, nu0.data, np.zeros(1))
+
+
+def test_state_control_recorder_hook_and_bulk_feeds(tmp_path):
+    """reference logging.StateControlRecorder (logging.py:31-247): the StepHook feed and the batched device-ring feed
+    log identical rows; the CSV on disk parses back to them; probe validation keeps the reference's errors."""
+    import csv
+
+    from mujoco_template_amd.logging import DataProbe, StateControlRecorder
+
+    def make():
+        return mt.Env.from_xml_path(MODELS["cartpole"], controller=mt.RandomCtrlController(seed=3, scale=0.01), batch=4)
+
+    env = make()
+    probe = DataProbe("pole_angle", lambda e, r: np.asarray(e.data.qpos)[2, 1])
+    path = tmp_path / "hook.csv"
+    with StateControlRecorder(env, log_path=path, probes=[probe], env_index=2) as rec:
+        n = runtime.run_passive_headless(env, max_steps=12, hooks=rec)
+    assert n == 12 and len(rec.rows) == 12
+    assert rec.columns == ("time_s", "qpos[slider]", "qvel[slider]", "qpos[hinge]", "qvel[hinge]", "ctrl[cart_force]", "pole_angle")
+    assert rec.rows[-1][0] == pytest.approx(12 * 0.01)
+    assert rec.rows[3][6] == rec.rows[3][2]      # reference row order: time, ALL qpos, ALL qvel, ctrl (logging.py:207-224)
+    with open(path, newline="") as f:
+        disk = list(csv.reader(f))
+    assert tuple(disk[0]) == rec.columns and len(disk) == 13 and float(disk[5][1]) == rec.rows[4][1]
+    # bulk feed on a fresh, identically seeded environment: same rows (no probes there)
+    env2 = make()
+    rec2 = StateControlRecorder(env2, env_index=2)
+    assert rec2.record_rollout(12, chunk=5) == 12
+    for a, b in zip(rec.rows, rec2.rows):
+        assert a[1:6] == pytest.approx(b[1:], rel=0, abs=0)
+        assert a[0] == pytest.approx(b[0], abs=1e-6)            # the device ring holds time in the data dtype (fp32)
+    # all environments: leading env column
+    env3 = make()
+    rec3 = StateControlRecorder(env3, env_index=None)
+    rec3.record_rollout(3)
+    assert rec3.columns[0] == "env" and len(rec3.rows) == 12 and [r[0] for r in rec3.rows[:4]] == [0, 1, 2, 3]
+    assert rec3.rows[2][1:] == pytest.approx(rec2.rows[0], abs=0)
+    assert next(rec3.as_dicts())["time_s"] == pytest.approx(0.01)
+    env4 = make()
+    rec4 = StateControlRecorder(env4, env_index=2, align_columns=True)
+    rec4.record_rollout(2)
+    assert (rec4.rows[1][1], rec4.rows[1][3], rec4.rows[1][2], rec4.rows[1][4]) == tuple(rec2.rows[1][1:5])
+    with pytest.raises(mt.ConfigError):
+        StateControlRecorder(env, probes=[probe, probe])
+    with pytest.raises(mt.ConfigError):
+        StateControlRecorder(env, probes=[DataProbe("", lambda e, r: 0.0)])
+    with pytest.raises(mt.ConfigError):
+        StateControlRecorder(env, env_index=7)
+    with pytest.raises(mt.ConfigError):
+        StateControlRecorder(env, probes=[probe]).record_rollout(2)
+    bad = StateControlRecorder(env, probes=[DataProbe("vec", lambda e, r: np.zeros(2))])
+    with pytest.raises(mt.ConfigError):
+        bad(env.step())

@@ -132,3 +132,34 @@ def test_gloo_world_size_2_all_gather_obs(tmp_path):
                         "--master-port", "29611", str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_recorder_schema_and_trajectory_logger(tmp_path):
+    """CSV schema of the reference's StateControlRecorder (logging.py:81-178): joint-major qpos/qvel columns with the
+    per-joint-type component suffixes, ctrl columns by actuator name, probes last; TrajectoryLogger row-length check."""
+    from mujoco_template_amd import mj
+    from mujoco_template_amd.exceptions import ConfigError
+    from mujoco_template_amd.logging import build_schema
+    from mujoco_template_amd.runtime import TrajectoryLogger
+    from tests.conftest import MODELS
+
+    m = mj.MjModel.from_xml_path(MODELS["cartpole"])
+    cols, qi, vi = build_schema(m, ["energy"])
+    assert cols == ("time_s", "qpos[slider]", "qvel[slider]", "qpos[hinge]", "qvel[hinge]", "ctrl[cart_force]", "energy")
+    assert qi == [0, 1] and vi == [0, 1]
+    h = mj.MjModel.from_xml_path(MODELS["humanoid"])
+    cols, qi, vi = build_schema(h)
+    assert cols[1:8] == tuple(f"qpos[root].{s}" for s in ("pos_x", "pos_y", "pos_z", "quat_w", "quat_x", "quat_y", "quat_z"))
+    assert cols[8:14] == tuple(f"qvel[root].{s}" for s in ("lin_x", "lin_y", "lin_z", "ang_x", "ang_y", "ang_z"))
+    assert len(cols) == 1 + h.nq + h.nv + h.nu and sorted(qi) == list(range(h.nq)) and sorted(vi) == list(range(h.nv))
+    assert cols[14].startswith("qpos[") and "." not in cols[14]          # hinge joints: one bare column
+    nu0 = mj.MjModel.from_xml_string("<mujoco><worldbody><body><joint type='hinge'/><geom size='0.1'/></body></worldbody></mujoco>")
+    assert build_schema(nu0)[0] == ("time_s", "qpos[joint_0]", "qvel[joint_0]", "ctrl[none]")
+    path = tmp_path / "sub" / "log.csv"
+    with TrajectoryLogger(path, ("a", "b"), lambda r: (r, 2 * r)) as lg:
+        assert lg.enabled and lg.log(3) == (3, 6)
+        with pytest.raises(ConfigError):
+            lg.write_row((1, 2, 3))
+    assert path.read_text().splitlines() == ["a,b", "3,6"]
+    with pytest.raises(ConfigError):
+        TrajectoryLogger(None, (), lambda r: ())
