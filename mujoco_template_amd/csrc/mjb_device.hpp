@@ -84,17 +84,10 @@ template <int G> MJB_DEV int gmaxi(int v) {
   }
   return v;
 }
-// maximum of group values that are all >= 0, and the lowest lane holding it (positive IEEE values order like integers)
-template <int G> MJB_DEV float gmaxpos(float v, int lane, int& who) {
-  const int key = __float_as_int(v), mx = gmaxi<G>(key);
-  who = -gmaxi<G>(key == mx ? -lane : -(1 << 30));
-  return __int_as_float(mx);
-}
-template <int G> MJB_DEV double gmaxpos(double v, int lane, int& who) {
-  const int hi = __double2hiint(v), lo = __double2loint(v) ^ (int)0x80000000;     // low word compared unsigned
-  const int mh = gmaxi<G>(hi), ml = gmaxi<G>(hi == mh ? lo : (int)0x80000000);
-  who = -gmaxi<G>((hi == mh && lo == ml) ? -lane : -(1 << 30));
-  return __hiloint2double(mh, ml ^ (int)0x80000000);
+// true if any lane of the group holds true (one wavefront per environment: a ballot)
+template <int G> MJB_DEV bool gany(bool v) {
+  if (G == 64) return __ballot(v) != 0ull;
+  return gsumi<G>((int)v) != 0;
 }
 template <int G> MJB_DEV int gscan_excl(int v, int lane, int& total) {
   int x = v;
@@ -1811,58 +1804,46 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
     gsync<G>();
     MJB_STAMP(c, PH_SOL_MV);
-    // Exact line search on the convex piecewise-quadratic f(alpha) = Gauss + sum_r 1/2 D_r min(0, jar_r + alpha jv_r)^2:
-    // f' is continuous, piecewise linear and increasing.
-    //  (1) f'(0) and f''(0+) over the rows active at alpha = 0 (not a descent direction -> alpha = 0);
-    //  (2) the Newton step a1 = -f'(0)/f''(0+) IS the minimiser when no row changes state between 0 and a1;
-    //  (3) otherwise every lane evaluates f' and the right-hand slope at ITS OWN ROW'S breakpoint -jar/jv against all
-    //      rows; from the last breakpoint with f' <= 0 one linear step lands on the root.  No iteration.
+    // Exact line search on the convex piecewise-quadratic f(alpha) = Gauss + sum_r 1/2 D_r min(0, jar_r + alpha jv_r)^2
+    // (f' continuous, piecewise linear, increasing): safeguarded Newton on f'.  A pure Newton step across which NO row
+    // changes state lands exactly on the root of the current linear piece: stop without a confirming evaluation.
+    // With nefc <= G every lane keeps its row (jar, jv, D jv) in registers: an iteration is a few VALU ops, two DPP
+    // reductions and a ballot.
     T alpha = 0;
     {
-      T* djs = w + L.efc_KBI;                                   // free since aref was formed (make_constraint)
-      T d1p = 0, d2p = 0;
-      for (int r = lane; r < nefc; r += G) {
-        T x = jar[r], jw = jv[r], dj = D[r] * jw;
-        djs[r] = dj;                                            // D jv, kept for step (3)
-        if (x < 0) { d1p += dj * x; d2p += dj * jw; }
-      }
-      const T d1 = g1 + gsum<T, G>(d1p), d2 = g2 + gsum<T, G>(d2p);
-      gsync<G>();
-#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
-      c.pacc[PH_CNT_LS] += 1;
-#endif
-      if (d1 < 0 && d2 >= Num<T>::minval()) {
-        const T a1 = -d1 / d2;
-        int flips = 0;
-        for (int r = lane; r < nefc; r += G) { T x0 = jar[r], x1 = x0 + a1 * jv[r]; flips |= (int)((x0 < 0) != (x1 < 0)); }
-        if (gsumi<G>(flips) == 0) alpha = a1;
-        else {
-#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
-          c.pacc[PH_CNT_LS] += 1;
-#endif
-          T bbp = 0, bf = d1, bsl = d2;                         // candidate "alpha = 0" (f'(0) = d1 < 0)
-          for (int r0 = 0; r0 < nefc; r0 += G) {
-            const int r = r0 + lane;
-            T bp = -1;
-            if (r < nefc) { T jw = jv[r]; if (jw != 0) bp = -jar[r] / jw; }
-            const bool valid = bp > 0 && bp < (T)1e30;
-            const T at = valid ? bp : (T)0;
-            T f = g1 + at * g2, sl = g2;
-            for (int q = 0; q < nefc; q++) {                    // uniform trip count; broadcast LDS reads
-              T jw = jv[q], x0 = jar[q], xs = x0 + at * jw, dj = djs[q];
-              // rows AT their breakpoint here (the lane's own row, and rows tied with it, e.g. the mirrored contacts of a
-              // symmetric stance: xs is rounding noise) switch on iff they are decreasing
-              const bool tie = q == r || t_abs(xs) <= (sizeof(T) == 4 ? (T)4e-7 : (T)1e-15) * (t_abs(x0) + at * t_abs(jw));
-              const bool act = tie ? (jw < 0) : (xs < 0);
-              if (act) { f += tie ? (T)0 : dj * xs; sl += dj * jw; }
-            }
-            if (valid && f <= 0 && bp > bbp) { bbp = bp; bf = f; bsl = sl; }
+      const bool inreg = nefc <= G;
+      T x0r = 0, jwr = 0, djr = 0;
+      if (inreg && lane < nefc) { x0r = jar[lane]; jwr = jv[lane]; djr = D[lane] * jwr; }
+      T lo = 0, hi = -1;
+      for (int it = 0; it < 50; it++) {
+        T d1p = 0, d2p = 0;
+        if (inreg) {
+          T x = x0r + alpha * jwr;
+          if (x < 0) { d1p = djr * x; d2p = djr * jwr; }
+        } else {
+          for (int r = lane; r < nefc; r += G) {
+            T x = jar[r] + alpha * jv[r];
+            if (x < 0) { T dj = D[r] * jv[r]; d1p += dj * x; d2p += dj * jv[r]; }
           }
-          int who;
-          const T aL = gmaxpos<G>(bbp, lane, who);
-          const T fL = gshfl<T, G>(bf, who), sL = gshfl<T, G>(bsl, who);
-          alpha = sL >= Num<T>::minval() ? aL - fL / sL : aL;
         }
+        T d1 = g1 + alpha * g2 + gsum<T, G>(d1p), d2 = g2 + gsum<T, G>(d2p);
+        if (it == 0 && d1 >= 0) { alpha = 0; break; }
+        if (d2 < Num<T>::minval()) break;
+        if (t_abs(d1) < (sizeof(T) == 4 ? (T)1e-6 : (T)1e-14) * (t_abs(g1) + Num<T>::minval())) break;
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        T an = alpha - d1 / d2;
+        bool newton = true;
+        if (an <= lo || (hi >= 0 && an >= hi)) { an = hi >= 0 ? (T)0.5 * (lo + hi) : 2 * alpha + (T)1e-3; newton = false; }
+        if (an == alpha) break;
+        bool flip = false;
+        if (inreg) flip = ((x0r + alpha * jwr) < 0) != ((x0r + an * jwr) < 0);
+        else for (int r = lane; r < nefc; r += G) flip |= ((jar[r] + alpha * jv[r]) < 0) != ((jar[r] + an * jv[r]) < 0);
+        const bool anyflip = gany<G>(flip);
+        alpha = an;
+#if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
+        c.pacc[PH_CNT_LS] += 1;
+#endif
+        if (newton && !anyflip) break;
       }
     }
     MJB_STAMP(c, PH_SOL_LS);

@@ -52,17 +52,7 @@ template <int G> static inline int gmaxi(int v) {
   emu::sync();
   return (int)s;
 }
-template <int G, typename T> static inline T gmaxpos(T v, int lane, int& who) {
-  emu::Group* g = emu::tl_group;
-  g->fbuf[emu::tl_lane] = (double)v;
-  emu::sync();
-  double mx = g->fbuf[0]; int w = 0;
-  for (int i = 1; i < g->G; i++) if (g->fbuf[i] > mx) { mx = g->fbuf[i]; w = i; }
-  emu::sync();
-  (void)lane;
-  who = w;
-  return (T)mx;
-}
+template <int G> static inline bool gany(bool v) { return gsumi<G>((int)v) != 0; }
 template <int G> static inline int gscan_excl(int v, int lane, int& total) {
   emu::Group* g = emu::tl_group;
   g->ibuf[lane] = v;
