@@ -550,6 +550,16 @@ MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane 
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(half == 0 ? p[0] : p[1]);
 }
+// v(lane) + v(lane ^ 32): the sum over the two 32-lane halves, in all 64 lanes
+MJB_DEV float half_sum(float v) {
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+MJB_DEV double half_sum(double v) {
+  auto ph = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  auto pl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  return __hiloint2double((int)ph[0], (int)pl[0]) + __hiloint2double((int)ph[1], (int)pl[1]);
+}
 // Backward substitution L^T x = y, 8 rows at a time.  rs holds x pre-scaled by the lane's own 1/L_cc, so the serial chain
 // per row is one v_readlane + one FMA; the next block's rows are loaded while the current chain runs.
 MJB_DEV void mfma_back_load8(float (&dst)[8], const float* Wc, int blk, int n) {
@@ -1702,6 +1712,26 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
 // ---------------------------------------------------------------------------
 // A10 Newton solver on the primal problem (limit / frictionless / pyramidal rows)
 // ---------------------------------------------------------------------------
+// (J^T f)_i for dof i = lane & 31 on the split path (one wavefront per environment, nv <= 32): the rows are split between
+// the two 32-lane halves and the partial sums exchanged with v_permlane32_swap - half the serial length of the dot.
+template <typename T, int G> MJB_DEV bool jt_split(int nv) {
+#ifndef MJB_HOST_EMU
+  return G == 64 && nv <= 32;
+#else
+  return false;
+#endif
+}
+template <typename T, int G> MJB_DEV T jt_dot(const T* J, const T* f, int nefc, int nv, int lane) {
+#ifndef MJB_HOST_EMU
+  const int h = lane >> 5, i = lane & 31, n2 = (nefc + 1) >> 1;
+  const int r0 = h ? n2 : 0, cnt = h ? nefc - n2 : n2;
+  T p = i < nv ? dot_lds(J + r0 * nv + i, nv, VecLds<T>{f + r0}, cnt) : (T)0;
+  return half_sum(p);
+#else
+  return (T)0;
+#endif
+}
+
 template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, bool store) {
   // Ma = M qacc, jar = J qacc - aref; returns Gauss + constraint cost.  store=false leaves force untouched.
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
@@ -1709,16 +1739,20 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   T *qs = w + L.qfrc_smooth, *qas = w + L.qacc_smooth;
   T part = 0;
   const VecBcast<T, G> xq(qacc, nv, lane);
-  for (int i = lane; i < nv; i += G) {
-    T s = dot_lds(M + i * nv, 1, xq, nv);
-    Ma[i] = s;
-    part += (T)0.5 * (s - qs[i]) * (qacc[i] - qas[i]);
-  }
-  for (int r = lane; r < nefc; r += G) {
-    T s = dot_lds(J + r * nv, 1, xq, nv) - aref[r];
-    jar[r] = s;
-    if (s < 0) { part += (T)0.5 * D[r] * s * s; if (store) force[r] = -D[r] * s; }
-    else if (store) force[r] = 0;
+  // rows of M and rows of J in ONE pass over the stacked matrix [M; J] (nv + nefc rows usually fit the 64 lanes)
+  for (int rho = lane; rho < nv + nefc; rho += G) {
+    const bool ism = rho < nv;
+    const int r = ism ? rho : rho - nv;
+    T s = dot_lds(ism ? M + r * nv : J + r * nv, 1, xq, nv);
+    if (ism) {
+      Ma[r] = s;
+      part += (T)0.5 * (s - qs[r]) * (qacc[r] - qas[r]);
+    } else {
+      s -= aref[r];
+      jar[r] = s;
+      if (s < 0) { part += (T)0.5 * D[r] * s * s; if (store) force[r] = -D[r] * s; }
+      else if (store) force[r] = 0;
+    }
   }
   T cost = gsum<T, G>(part);
   gsync<G>();
@@ -1741,10 +1775,16 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
     dw[r] = act ? D[r] : (T)0;
   }
   T gpart = 0;
-  for (int i = lane; i < nv; i += G) {
-    T g = Ma[i] - qs[i] - dot_lds(J + i, nv, VecLds<T>{force}, nefc);
-    grad[i] = g; search[i] = g;
-    gpart += g * g;
+  if (jt_split<T, G>(nv)) {
+    const int i = lane & 31;
+    T jf = jt_dot<T, G>(J, force, nefc, nv, lane);
+    if (lane < nv) { T g = Ma[i] - qs[i] - jf; grad[i] = g; search[i] = g; gpart = g * g; }
+  } else {
+    for (int i = lane; i < nv; i += G) {
+      T g = Ma[i] - qs[i] - dot_lds(J + i, nv, VecLds<T>{force}, nefc);
+      grad[i] = g; search[i] = g;
+      gpart += g * g;
+    }
   }
   T gn = gsum<T, G>(gpart);
   const bool rebuild = (MJB_SWEEP_EXCLUDE != 1 && fused_inverse_path<T, G>(nv)) || gsumi<G>(chg) != 0;   // the sweep path keeps no factor
@@ -1793,13 +1833,12 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
     const VecBcast<T, G> xs(search, nv, lane);
-    for (int i = lane; i < nv; i += G) {
-      T sacc = dot_lds(M + i * nv, 1, xs, nv);
-      Mv[i] = sacc;
-      p1 += search[i] * (Ma[i] - qs[i]); p2 += search[i] * sacc;
-    }
-    for (int r = lane; r < nefc; r += G) {
-      jv[r] = dot_lds(J + r * nv, 1, xs, nv);
+    for (int rho = lane; rho < nv + nefc; rho += G) {          // stacked [M; J] x search, one pass
+      const bool ism = rho < nv;
+      const int r = ism ? rho : rho - nv;
+      T sacc = dot_lds(ism ? M + r * nv : J + r * nv, 1, xs, nv);
+      if (ism) { Mv[r] = sacc; p1 += search[r] * (Ma[r] - qs[r]); p2 += search[r] * sacc; }
+      else jv[r] = sacc;
     }
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
     gsync<G>();
@@ -1865,8 +1904,11 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     c.niter = iter + 1;
     if (scale * (old - cost) < m.tolerance) break;
   }
-  for (int i = lane; i < nv; i += G) {
-    qc[i] = dot_lds(J + i, nv, VecLds<T>{force}, nefc); ws[i] = qacc[i];
+  if (jt_split<T, G>(nv)) {
+    T jf = jt_dot<T, G>(J, force, nefc, nv, lane);
+    if (lane < nv) { qc[lane] = jf; ws[lane] = qacc[lane]; }
+  } else {
+    for (int i = lane; i < nv; i += G) { qc[i] = dot_lds(J + i, nv, VecLds<T>{force}, nefc); ws[i] = qacc[i]; }
   }
   gsync<G>();
 }
