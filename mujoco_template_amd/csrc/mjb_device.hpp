@@ -1150,8 +1150,7 @@ template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
     for (int k = 0; k < 6; k++) buf[6 * i + k] = r[k];
   }
   gsync<G>();
-  for (int idx = lane; idx < nv * nv; idx += G) M[idx] = 0;
-  gsync<G>();
+  // entries of M outside the (dof, ancestor-dof) pairs are structurally zero and never written: cleared once per launch (env_run)
   for (int idx = lane; idx < m.nmpair; idx += G) {
     int pr = m.mpair[idx], i = pr >> 8, j = pr & 0xff;      // j is i or one of its ancestor dofs
     T val = 0;
@@ -2132,7 +2131,7 @@ template <typename T, typename TS, int G> MJB_DEV void inverse_dynamics(Ctx<T>& 
 template <typename T, int G> MJB_DEV bool group_bad(const T* x, int n, int lane) {
   int bad = 0;
   for (int i = lane; i < n; i += G) { T v = x[i]; if (!(t_abs(v) <= (T)1e10)) bad = 1; }
-  return gsumi<G>(bad) != 0;
+  return gany<G>(bad != 0);
 }
 template <typename T, int G> MJB_DEV void reset_state(Ctx<T>& c) {
   MJB_ENV(c); T* w = c.w;
@@ -2179,6 +2178,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     w[L.qacc + i] = (T)d.qacc[(size_t)env * nv + i];
   }
   for (int i = lane; i < nu; i += G) w[L.ctrl + i] = a.ctrl_mode == CTRL_ZERO ? (T)0 : (T)d.ctrl[(size_t)env * nu + i];
+  for (int i = lane; i < nv * nv; i += G) w[L.M + i] = 0;       // structural zeros of the mass matrix (crb_factor fills the rest)
   double time = d.time[env];
   int badqpos = 0, badqvel = 0, badqacc = 0;
   gsync<G>();

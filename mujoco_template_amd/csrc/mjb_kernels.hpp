@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void k_fd(const DevModel<T>* mg, const Lay* lg,
     w[L.Mv + i] = 0;
   }
   for (int i = lane; i < nu; i += G) w[L.ctrl + i] = (T)d.ctrl[(size_t)env * nu + i];
+  for (int i = lane; i < nv * nv; i += G) w[L.M + i] = 0;       // structural zeros of the mass matrix (crb_factor fills the rest)
   gsync<G>();
   int ok = 1;
   if (col > 0) {

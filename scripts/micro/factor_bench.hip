@@ -21,7 +21,11 @@ __global__ __launch_bounds__(64, 2) void kb(int n, int nefc, int mode, int iters
   for (int it = 0; it < iters; it++) {
     if (lane < n) x[lane] = 1.0f + 0.01f * lane;
     __syncthreads();
+#ifdef MICRO_CHOL
+    mjb::mfma_factor32<MiniRef>(m, M, W, dinv, J, dw, nefc, mode, n, lane, x, pf);
+#else
     mjb::mfma_sweep_solve32<MiniRef>(m, M, dinv, J, dw, nefc, mode, n, lane, x, pf);
+#endif
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (lane == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = pf[0]; cyc[2] = pf[1]; cyc[3] = pf[2]; }
