@@ -89,6 +89,21 @@ template <int G> MJB_DEV bool gany(bool v) {
   if (G == 64) return __ballot(v) != 0ull;
   return gsumi<G>((int)v) != 0;
 }
+// exclusive prefix sum over the group for SMALL counts (0 <= v < 8): three ballots + population counts, no LDS crossbar
+template <int G> MJB_DEV int gscan_small(int v, int lane, int& total) {
+  const int wl = (int)(threadIdx.x & 63);
+  const unsigned long long gm = G == 64 ? ~0ull : (((1ull << (G & 63)) - 1ull) << (wl - lane));
+  const unsigned long long lt = gm & ((1ull << wl) - 1ull);
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const unsigned long long mk = __ballot((v >> b) & 1);
+    pre += __popcll(mk & lt) << b;
+    tot += __popcll(mk & gm) << b;
+  }
+  total = tot;
+  return pre;
+}
 template <int G> MJB_DEV int gscan_excl(int v, int lane, int& total) {
   int x = v;
 #pragma unroll
@@ -1287,7 +1302,7 @@ template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
         n = nc_sphere_sphere(v1, s1[0], v2, s2[0], margin, rc[0]);
       }
     }
-    int total, off = gscan_excl<G>(n, lane, total);
+    int total, off = gscan_small<G>(n, lane, total);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (k < n) {
@@ -1360,40 +1375,46 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
   int *etype = c.wi + L.i_efc_type, *con_pair = c.wi + L.i_con_pair;   // etype: bits 0-7 type, 8 active-at-last-factor, 9.. object id
   T *con = w + L.con, *tl = w + L.ten_length, *tj = w + L.ten_J;
   int nefc = 0, dropped = 0;
-  // joint limits, then tendon limits: object `o`, side -1 (lower) then +1 (upper)
-  for (int pass = 0; pass < 2; pass++) {
-    int nobj = pass == 0 ? m.njnt : m.ntendon;
+  // joint limits, then tendon limits, in ONE lane-parallel pass over the njnt + ntendon objects (rows keep that order):
+  // object `o`, side 0 (lower) then 1 (upper)
+  {
+    const int nobj = m.njnt + m.ntendon;
     for (int base = 0; base < nobj; base += G) {
-      int o = base + lane, cnt = 0;
+      const int k = base + lane;
+      const bool isj = k < m.njnt;
+      const int o = isj ? k : k - m.njnt;
+      int cnt = 0;
       T dist[2] = {0, 0}, margin = 0;
       bool act[2] = {false, false};
-      if (o < nobj) {
-        bool lim = pass == 0 ? (m.jnt_limited[o] && (m.jnt_type[o] == JNT_HINGE || m.jnt_type[o] == JNT_SLIDE)) : (m.tendon_limited[o] != 0);
+      if (k < nobj) {
+        bool lim = isj ? (m.jnt_limited[o] && (m.jnt_type[o] == JNT_HINGE || m.jnt_type[o] == JNT_SLIDE)) : (m.tendon_limited[o] != 0);
         if (lim) {
-          T value = pass == 0 ? qpos[m.jnt_qposadr[o]] : tl[o];
-          auto rng = pass == 0 ? m.jnt_range + 2 * o : m.tendon_range + 2 * o;
-          margin = pass == 0 ? m.jnt_margin[o] : m.tendon_margin[o];
+          T value = isj ? qpos[m.jnt_qposadr[o]] : tl[o];
+          auto rng = isj ? m.jnt_range + 2 * o : m.tendon_range + 2 * o;
+          margin = isj ? m.jnt_margin[o] : m.tendon_margin[o];
           dist[0] = value - rng[0]; dist[1] = rng[1] - value;
           act[0] = dist[0] < margin; act[1] = dist[1] < margin;
           cnt = (int)act[0] + (int)act[1];
         }
       }
-      int total, off = gscan_excl<G>(cnt, lane, total);
+      int total, off = gscan_small<G>(cnt, lane, total);
       int row = nefc + off;
+      if (cnt > 0) {
+        auto solref = isj ? m.jnt_solref + 2 * o : m.tendon_solref + 2 * o;
+        auto solimp = isj ? m.jnt_solimp + 5 * o : m.tendon_solimp + 5 * o;
+        T sr[2] = {solref[0], solref[1]}, si[5] = {solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
+        T diag = isj ? m.dof_invweight0[m.jnt_dofadr[o]] : m.tendon_invweight0[o];
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
-        if (act[s]) {
-          if (row < cap) {
-            auto solref = pass == 0 ? m.jnt_solref + 2 * o : m.tendon_solref + 2 * o;
-            auto solimp = pass == 0 ? m.jnt_solimp + 5 * o : m.tendon_solimp + 5 * o;
-            T sr[2] = {solref[0], solref[1]}, si[5] = {solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
-            T diag = pass == 0 ? m.dof_invweight0[m.jnt_dofadr[o]] : m.tendon_invweight0[o];
-            T K, B, imp, R;
-            row_params(m, dist[s], margin, sr, si, diag, K, B, imp, R);
-            etype[row] = (pass == 0 ? EFC_LIMIT_JOINT : EFC_LIMIT_TENDON) | ((o * 2 + s) << 9);
-            epos[row] = dist[s]; emargin[row] = margin; eD[row] = 1 / R; eK[row] = K; eB[row] = B; eI[row] = imp;
+        for (int sd = 0; sd < 2; sd++) {
+          if (act[sd]) {
+            if (row < cap) {
+              T K, B, imp, R;
+              row_params(m, dist[sd], margin, sr, si, diag, K, B, imp, R);
+              etype[row] = (isj ? EFC_LIMIT_JOINT : EFC_LIMIT_TENDON) | ((o * 2 + sd) << 9);
+              epos[row] = dist[sd]; emargin[row] = margin; eD[row] = 1 / R; eK[row] = K; eB[row] = B; eI[row] = imp;
+            }
+            row++;
           }
-          row++;
         }
       }
       int newn = nefc + total;
@@ -1412,7 +1433,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
       incm = m.pair_margin[p] - m.pair_gap[p];
       if (dist < incm) rows = m.pair_condim[p] == 1 ? 1 : 4;
     }
-    int total, off = gscan_excl<G>(rows, lane, total);
+    int total, off = gscan_small<G>(rows, lane, total);
     int row = nefc + off;
     if (ci < c.ncon) {
       bool fits = rows > 0 && row + rows <= cap;

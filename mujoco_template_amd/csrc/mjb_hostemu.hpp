@@ -63,6 +63,7 @@ template <int G> static inline int gscan_excl(int v, int lane, int& total) {
   total = (int)t;
   return (int)s;
 }
+template <int G> static inline int gscan_small(int v, int lane, int& total) { return gscan_excl<G>(v, lane, total); }
 template <typename T, int G> static inline T gshfl(T v, int src) {
   emu::Group* g = emu::tl_group;
   g->fbuf[emu::tl_lane] = (double)v;
