@@ -1831,16 +1831,14 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   }
   T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *jv = w + L.efc_jv, *D = w + L.efc_D, *force = w + L.efc_force;
   T *search = w + L.search, *Mv = w + L.Mv, *qs = w + L.qfrc_smooth;
-  // warmstart(): best of (qacc_warmstart, qacc_smooth).  pass 0: warmstart, pass 1: smooth, pass 2: warmstart again if it won
-  T cost = 0, cost_ws = 0;
-  for (int pass = 0; pass < 3; pass++) {
-    const T* x = pass == 1 ? qas : ws;
-    T cst = solver_cost<T, G>(c, x, true);
-    if (pass == 0) cost_ws = cst;
-    else if (pass == 1) {
-      cost = cst;
-      if (!(cost_ws < cst)) { for (int i = lane; i < nv; i += G) qacc[i] = qas[i]; break; }
-    } else { cost = cst; for (int i = lane; i < nv; i += G) qacc[i] = ws[i]; }
+  // warmstart(): best of (qacc_warmstart, qacc_smooth) as the starting point.  The unconstrained point is evaluated FIRST so
+  // that in the common case (the warm start wins) Ma / jar / force are already those of the chosen point: two cost
+  // evaluations instead of three; same costs, same decision (warm start only if strictly cheaper).
+  T cost = solver_cost<T, G>(c, qas, true);
+  {
+    const T cost_ws = solver_cost<T, G>(c, ws, true);
+    if (cost_ws < cost) { cost = cost_ws; for (int i = lane; i < nv; i += G) qacc[i] = ws[i]; }
+    else { cost = solver_cost<T, G>(c, qas, true); for (int i = lane; i < nv; i += G) qacc[i] = qas[i]; }
   }
   gsync<G>();
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
