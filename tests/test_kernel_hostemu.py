@@ -119,3 +119,41 @@ def test_inverse_dynamics_matches_oracle(compiled, name, G):
     assert np.abs(e.qfrc_inverse - od.qfrc_inverse).max() < 1e-10 * s
     assert np.abs(e.actuator_moment[: cm.nu * cm.nv] - od.actuator_moment).max() < 1e-12
     assert np.abs(e.qacc - od.qacc).max() == 0            # state untouched
+
+
+def test_more_bodies_than_lanes_takes_the_slow_tree_paths():
+    """nbody > G: the per-lane register schedule of the tree passes (kinematics composition, velocity prefix sums, subtree
+    rounds) falls back to its strided loop.  A branching tree of 13 bodies with 3 dofs on 8 lanes, vs the oracle."""
+    from mujoco_template_amd import mjcf
+
+    def limb(name, depth):
+        if depth == 0:
+            return ""
+        return (f"<body name='{name}{depth}' pos='0.1 0.02 -0.15' euler='0 10 5'><geom type='capsule' size='0.02' fromto='0 0 0 0.1 0 -0.1'/>"
+                + limb(name, depth - 1) + "</body>")
+
+    xml = f"""<mujoco><option timestep='0.004' gravity='0 0 -9.81'/>
+      <worldbody><geom name='floor' type='plane' size='2 2 0.1'/>
+        <body name='root' pos='0 0 1.0'><joint name='j0' type='hinge' axis='0 1 0' damping='0.1'/>
+          <geom type='capsule' size='0.03' fromto='0 0 0 0 0 -0.3'/>
+          <body name='a' pos='0 0 -0.3'><joint name='j1' type='hinge' axis='1 0 0' damping='0.05' limited='true' range='-40 40'/>
+            <geom type='sphere' size='0.05'/>{limb('l', 5)}{limb('r', 4)}
+          </body>
+          <body name='b' pos='0.1 0 -0.1'><joint name='j2' type='slide' axis='0 0 1' damping='0.2'/><geom type='box' size='0.03 0.03 0.03' contype='0' conaffinity='0'/></body>
+        </body></worldbody>
+      <actuator><motor joint='j0' gear='2'/><motor joint='j2' gear='1'/></actuator></mujoco>"""
+    cm = mjcf.compile_xml_string(xml)
+    assert cm.nbody == 13 and cm.nv == 3
+    od = mjo.OracleData(mjo.OracleModel(cm))
+    e = EmuEnv(cm, G=8)
+    rng = np.random.default_rng(4)
+    q = rng.normal(size=cm.nq) * 0.3; v = rng.normal(size=cm.nv); u = rng.uniform(-1, 1, size=cm.nu)
+    od.qpos[:] = q; od.qvel[:] = v; od.ctrl[:] = u
+    e.qpos[:] = q; e.qvel[:] = v; e.ctrl[:cm.nu] = u
+    od.forward(); e.forward()
+    for k in ("xpos", "xipos", "subtree_com", "cdof", "cinert", "cvel", "qM", "qfrc_bias", "qfrc_passive", "qacc"):
+        a, b = getattr(e, k), getattr(od, k)
+        assert np.abs(a[:b.size] - b).max() <= 1e-11 * max(1.0, float(np.abs(b).max())), k
+    for _ in range(30):
+        od.step(); e.step()
+    assert np.abs(e.qpos - od.qpos).max() < 1e-10 and np.abs(e.qvel - od.qvel).max() < 1e-9
