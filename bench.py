@@ -41,6 +41,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nefcmax", type=int, default=0)
     ap.add_argument("--nconmax", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-process path (observations staged through the host)")
+    ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -54,9 +56,11 @@ def main() -> None:
     if ws != args.gpus:
         if rank == 0 and ws > 1:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={ws}; using WORLD_SIZE", file=sys.stderr)
-    distributed = init_process_group("nccl") if ws > 1 else False
-    device = local if ws > 1 else 0
+    if args.all_ranks_device0 and args.backend == "nccl":
+        raise SystemExit("--all-ranks-device0 needs --backend gloo (RCCL refuses two ranks on one GPU)")
+    device = 0 if (ws == 1 or args.all_ranks_device0) else local
     torch.cuda.set_device(device)
+    distributed = init_process_group(args.backend) if ws > 1 else False
 
     xml = {"humanoid": "models/humanoid.xml", "cartpole": "models/cartpole.xml", "drone2": "models/drone2/scene.xml",
            "pendulum": "models/pendulum.xml"}[args.model]
@@ -64,9 +68,11 @@ def main() -> None:
     if args.weak:
         env0, count = rank * args.global_batch, args.global_batch
         global_batch = args.global_batch * ws
+        counts = [args.global_batch] * ws
     else:
         env0, count = shard_range(args.global_batch, rank, ws)
         global_batch = args.global_batch
+        counts = [shard_range(args.global_batch, r, ws)[1] for r in range(ws)]
 
     env = Env.from_xml_path(os.path.join(ROOT, xml), obs_spec=ObservationSpec(as_dict=False),
                             controller=RandomCtrlController(seed=0, scale=scale), batch=count, dtype="float32", device=device,
@@ -87,7 +93,7 @@ def main() -> None:
             if events is not None:
                 e1.record()
                 events.append((e0, e1, n))
-            all_gather_obs(obs)                            # RCCL all-gather of the ObservationExtractor output
+            all_gather_obs(obs, counts=counts)             # RCCL all-gather of the ObservationExtractor output (sizes known: no size exchange)
             done += n
 
     def barrier() -> None:
@@ -172,15 +178,15 @@ def cpu_baseline(xml_path: str, scale: float) -> dict:
     om = mjo.OracleModel(compile_xml_path(xml_path))
     cores = min(os.cpu_count() or 1, 16)
     mjo.rollout_batch(om, cores, 20, seed=0, scale=scale, nthreads=cores)          # warm-up
-    nenv, nstep = 8 * cores, 500
+    nenv, nstep = 64 * cores, 2000            # ~2 M env-steps: a few seconds of wall time on 16 cores (tens of core-seconds)
     t = time.perf_counter()
     mjo.rollout_batch(om, nenv, nstep, seed=0, scale=scale, nthreads=cores)
     dt = time.perf_counter() - t
     t1 = time.perf_counter()
-    mjo.rollout_batch(om, 4, nstep, seed=0, scale=scale, nthreads=1)
+    mjo.rollout_batch(om, 16, nstep, seed=0, scale=scale, nthreads=1)
     dt1 = time.perf_counter() - t1
     return {"value": nenv * nstep / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "single_core_value": 4 * nstep / dt1,
+            "single_core_value": 16 * nstep / dt1,
             "sample": f"{nenv} envs x {nstep} steps of the same random-ctrl rollout, float64 C oracle, one env per OpenMP task; "
                       "the reference's own CPU loop (mujoco wheel) is not runnable here"}
 

@@ -44,11 +44,13 @@ def init_process_group(backend: str | None = None) -> bool:
     return True
 
 
-def all_gather_obs(local_obs, global_batch: int | None = None):
+def all_gather_obs(local_obs, global_batch: int | None = None, counts=None):
     """All-gather ``[..., b_local, dim]`` blocks along the batch axis (axis -2) into ``[..., B, dim]``.
 
     Equal shards use one ``all_gather_into_tensor`` (a single RCCL collective); ragged shards
     fall back to ``all_gather`` with padding.  Without an initialised process group this is the identity.
+    ``counts`` (per-rank shard sizes, e.g. from ``shard_range``) skips the size exchange and its host sync.
+    With the ``gloo`` backend CUDA blocks are staged through the host (rehearsals on one GPU).
     """
     import torch
     import torch.distributed as dist
@@ -57,9 +59,15 @@ def all_gather_obs(local_obs, global_batch: int | None = None):
         return local_obs
     ws = dist.get_world_size()
     x = local_obs.movedim(-2, 0).contiguous()                  # [b_local, ..., dim]
-    sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(ws)]
-    dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
-    counts = [int(s.item()) for s in sizes]
+    home = x.device
+    if x.is_cuda and dist.get_backend() == "gloo":
+        x = x.cpu()
+    if counts is None:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(ws)]
+        dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+        counts = [int(s.item()) for s in sizes]
+    elif len(counts) != ws or counts[dist.get_rank()] != x.shape[0]:
+        raise ValueError("counts does not match the process group / the local block")
     if len(set(counts)) == 1:
         out = torch.empty((ws * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x)
@@ -70,7 +78,7 @@ def all_gather_obs(local_obs, global_batch: int | None = None):
         parts = [torch.empty_like(pad) for _ in range(ws)]
         dist.all_gather(parts, pad)
         out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
-    return out.movedim(0, -2)
+    return out.to(home).movedim(0, -2)
 
 
 __all__ = ["world", "shard_range", "init_process_group", "all_gather_obs"]
