@@ -654,9 +654,9 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     // so that the serial chain per panel is rsq -> fma -> rsq
     float v0 = half_bcast(acc[ij], hj), v1r = half_bcast(acc[ij + 1], hj);
     float a = __builtin_fmaxf(rdlane_f(v0, j0), Num<float>::minval()), b = rdlane_f(v0, j1), d = rdlane_f(v1r, j1);
-    float inv0 = t_rsqrt(a), bia = b * inv0 * inv0;
+    float inv0 = __builtin_amdgcn_rsqf(a), bia = b * inv0 * inv0;            // v_rsq_f32: 1 ulp, no refinement step on the chain
     float d1 = __builtin_fmaxf(d - b * bia, Num<float>::minval());
-    float inv1 = t_rsqrt(d1);
+    float inv1 = __builtin_amdgcn_rsqf(d1);
     float v1 = v1r - bia * v0;
     float L0 = c > j0 ? v0 * inv0 : (c == j0 ? a * inv0 : 0.0f);
     float L1 = c > j1 ? v1 * inv1 : (c == j1 ? d1 * inv1 : 0.0f);
