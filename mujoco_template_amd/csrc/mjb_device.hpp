@@ -642,7 +642,8 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
   float r = (x && c_ < n) ? x[c_] : 0.0f;                     // RHS replicated in both halves (lane -> row c)
   float myinv = 1.0f;
   const int wrow = tri_at(c_, 0), cvalid = (h == 0 && c_ < n) ? 0 : -1;
-  const int dump = (int)((dinv + n) - W);                     // one spare word behind dinv swallows the masked stores
+  float* const wrowp = W + wrow;
+  float* const dumpp = dinv + n;                              // one spare word behind dinv swallows the masked stores
   unsigned long long tq1 = pf ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
   for (int jb = 0; jb < 16; jb++) {
@@ -667,8 +668,10 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     r = c > j1 ? r - L0 * y0 - L1 * y1 : (c == j1 ? y1 : (c == j0 ? y0 : r));
     // packed factor to LDS for the backward substitution / later reuse; masked lanes write the dump word
     int cc = c | cvalid;
-    W[cc >= j0 ? wrow + j0 : dump] = L0;
-    W[cc >= j1 ? wrow + j1 : dump] = L1;
+    float* p0 = cc >= j0 ? wrowp : dumpp - j0;                // select between two lane-constant pointers: the column index
+    float* p1 = cc >= j1 ? wrowp : dumpp - j1;                // rides in the DS instruction's immediate offset
+    p0[j0] = L0;
+    p1[j1] = L1;
     // rank-2 trailing update of the whole matrix: acc -= [L0 L1] [L0 L1]^T
     float av = h == 0 ? L0 : L1;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-av, av, acc, 0, 0, 0);
