@@ -234,16 +234,21 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
   if (lanes != 8 && lanes != 16 && lanes != 64) return fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64");
   mjbData* d = new mjbData();
   d->model = m; d->batch = batch; d->dtype = dtype; d->G = lanes; d->device = device; d->env0 = env0; d->stream = nullptr;
-  // Caps on contacts / constraint rows held in LDS per environment.  Explicit values are taken as given; the default
-  // is the largest (rows <= 96, contacts = 3/8 rows) that still lets 8 fp32 (4 fp64) environments share one CU's
-  // 160 KiB — the occupancy step that matters most for throughput (profiles/).  Overflow drops rows and is COUNTED.
+  // Caps on contacts / constraint rows held in LDS per environment.  Explicit values are taken as given.  Default: the
+  // model's own worst case when that is small (<= 96 rows, <= 32 contacts); otherwise the largest (rows <= 96, contacts =
+  // 3/8 rows) that still lets 8 fp32 (4 fp64) wavefronts share one CU's 160 KiB — the occupancy step that matters most
+  // for throughput (profiles/).  Overflow drops rows and is COUNTED.
   if (nconmax > 0 || nefcmax > 0) {
     d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 32 ? h.ncon_alloc : 32);
     d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 96 ? h.nefc_alloc : 96);
   } else {
     const size_t budget = (size_t)160 * 1024 / (dtype == MJB_F32 ? 8 : 4);
     int ne = h.nefc_alloc < 96 ? h.nefc_alloc : 96, nc = 0;
-    for (;; ne -= 8) {
+    if (h.nefc_alloc <= 96 && h.ncon_alloc <= 32) {
+      // the model's own worst case (every candidate pair in contact, every limit active) is small: hold all of it, nothing
+      // can ever be dropped (drone2: 20 contacts / 80+ rows when it lands flat); occupancy is not traded against that
+      ne = h.nefc_alloc; nc = h.ncon_alloc;
+    } else for (;; ne -= 8) {
       nc = ne * 3 / 8; if (nc < 8) nc = 8; if (nc > h.ncon_alloc) nc = h.ncon_alloc;
       Lay t = make_layout(h, nc > 0 ? nc : 1, ne > 0 ? ne : 1, dtype == MJB_F32 ? sizeof(float) : sizeof(double));
       if ((size_t)(64 / lanes) * (size_t)t.bytes <= budget || ne <= 32) break;

@@ -408,3 +408,38 @@ def test_inverse_dynamics_matches_oracle(world, name, dtype, tol):
         assert np.abs(got[e] - ref).max() <= tol * max(1.0, np.abs(ref).max()), e
         assert np.abs(mom[e] - ods[e].actuator_moment).max() <= (1e-12 if dtype == "float64" else 1e-5)
     assert np.array_equal(sim.get("qacc"), a if dtype == "float64" else a.astype(np.float32).astype(np.float64))
+
+
+def test_config5_drone_contacts_flat_observation_gather_full_size(world):
+    """BASELINE config 5: drone2, batch 2048, ObservationSpec(sites, bodies, as_dict=False) gathered on the device every
+    step; half the batch starts at the hover keyframe, half is dropped onto the floor from z = 0.1 so that contacts occur
+    (SURVEY §8d).  Layout bodies_pos(3) | qpos(7) | qvel(6) | sites_pos(15) = 31 floats; the observation ring is checked
+    against the state arrays, and a sample of environments against the float64 oracle over the pre-contact horizon."""
+    import mujoco_template_amd as mt
+
+    cm, om, dm = world("drone2")
+    B, T = 2048, 200
+    spec = mt.ObservationSpec(sites_pos=("imu", "thrust1", "thrust2", "thrust3", "thrust4"), bodies_pos=("x2",), as_dict=False)
+    env = mt.Env.from_xml_path(MODELS["drone2"], obs_spec=spec, controller=mt.RandomCtrlController(seed=5, scale=0.3), batch=B)
+    key_qpos = np.array(cm.arrays["key_qpos"]).reshape(-1, cm.nq)[0]
+    q0 = np.tile(key_qpos, (B, 1)); q0[B // 2:, 2] = 0.1
+    env.data.qpos[...] = q0; env.data.qvel[...] = 0.0
+    ring = env.rollout(T, obs_every=1).cpu().numpy()                     # [T, B, 31]
+    assert ring.shape == (T, B, 31) and np.isfinite(ring).all()
+    sim = env.data.sim
+    qpos, qvel, xpos, site = sim.get("qpos"), sim.get("qvel"), sim.get("xpos").reshape(B, cm.nbody, 3), sim.get("site_xpos").reshape(B, cm.nsite, 3)
+    assert np.array_equal(ring[-1][:, 3:10], qpos.astype(np.float32)) and np.array_equal(ring[-1][:, 10:16], qvel.astype(np.float32))
+    cn = env.data.counters()
+    assert cn["ncon"][B // 2:].max() > 0 and int(cn["con_dropped"].sum()) == 0 and int(cn["efc_dropped"].sum()) == 0
+    assert np.abs(np.linalg.norm(qpos[:, 3:7], axis=1) - 1).max() < 1e-5
+    # site / body blocks: positions of the LAST forward pass (pre-integration state of the last step), like the state arrays
+    bid = cm.name2id(mjcf.OBJ_BODY, "x2")
+    assert ring[-1][:, 0:3] == pytest.approx(xpos[:, bid], abs=1e-6)
+    sid = [cm.name2id(mjcf.OBJ_SITE, n) for n in ("imu", "thrust1", "thrust2", "thrust3", "thrust4")]
+    assert ring[-1][:, 16:31].reshape(B, 5, 3) == pytest.approx(site[:, sid], abs=1e-6)
+    # oracle on a sample (hovering half: no contact, smooth): fp32 drift <= 1e-4 over 100 steps
+    for e in (0, 7, 1023):
+        od = mjo.OracleData(om)
+        od.qpos[:] = q0[e]
+        od.rollout_random(100, seed=5, env=e, scale=0.3)
+        assert np.abs(ring[99][e, 3:10] - od.qpos).max() < 1e-4, e
