@@ -41,6 +41,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nefcmax", type=int, default=0)
     ap.add_argument("--nconmax", type=int, default=0)
+    ap.add_argument("--no-specialize", action="store_true", help="use the generic step kernel instead of the per-model specialised one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-process path (observations staged through the host)")
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -76,7 +77,7 @@ def main() -> None:
 
     env = Env.from_xml_path(os.path.join(ROOT, xml), obs_spec=ObservationSpec(as_dict=False),
                             controller=RandomCtrlController(seed=0, scale=scale), batch=count, dtype="float32", device=device,
-                            env0=env0, nefcmax=args.nefcmax, nconmax=args.nconmax)
+                            env0=env0, nefcmax=args.nefcmax, nconmax=args.nconmax, specialize=False if args.no_specialize else None)
     sim = env.data.sim
     sim.use_torch_stream()
     obs_dim = env.extractor.obs_dim
@@ -152,9 +153,9 @@ def main() -> None:
                        "global_batch": global_batch, "per_gpu_batch": count, "rollout_steps": args.steps,
                        "fused_steps_per_launch": args.chunk, "obs_dim": obs_dim, "parallelism": f"env-shard x{ws}",
                        "lanes_per_env": sim.lanes, "lds_bytes_per_env": sim.lds_bytes_per_env,
-                       "nefcmax": sim.nefcmax, "nconmax": sim.nconmax},
+                       "nefcmax": sim.nefcmax, "nconmax": sim.nconmax, "specialized_kernel": bool(sim.specialized)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "mjb::k_step<float,float,%d>" % sim.lanes,
+                         "traffic": traffic, "kernel": ("mjb_k_step_spec (k_step<float,float,%d> with the model's sizes/offsets folded in)" if sim.specialized else "mjb::k_step<float,float,%d>") % sim.lanes,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_env_step": bytes_step, "obs_bytes_per_env": bytes_obs,
                          "note": "fused step is VALU/LDS-latency bound by construction (SURVEY.md §8d); see DESIGN.md for VALU/LDS counters"},
             "solver": {"mean_nefc_last_step": float(counters["nefc"].mean()), "max_nefc_last_step": int(counters["nefc"].max()),

@@ -71,6 +71,17 @@ int mjb_get_array(mjbData* d, const char* name, double* host_out);
 int mjb_set_array(mjbData* d, const char* name, const double* host_in);
 int mjb_get_counters(mjbData* d, int* host_out /* [batch, 8] */);
 
+/* ---- per-model specialisation of the fp32 step kernel (no reference counterpart: the reference's MjModel is interpreted by
+ * one pre-built C library; here the structural sizes of the compiled model and the LDS layout offsets can be folded into the
+ * kernel).  mjb_model_spec_source / mjb_spec_source write the translation unit (returns its length; call with buf = NULL to
+ * size it); compile it for gfx950 with `hipcc --genco -I <csrc>` (mujoco_template_amd/_capi.py does, cached in-tree) and hand
+ * the code object to mjb_spec_load: every later launch on this data object uses it (same arguments, same results).
+ * The generic kernel stays the default and the fallback. ---- */
+long mjb_model_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int nefcmax, char* buf, long cap);
+long mjb_spec_source(mjbData* d, char* buf, long cap);
+int mjb_spec_load(mjbData* d, const void* code_object, long nbytes);
+int mjb_spec_unload(mjbData* d);
+
 /* mj_resetData / mj_resetDataKeyframe (reference model.py:59-71); key < 0 = qpos0 */
 int mjb_reset(mjbData* d, int key);
 /* mj_forward (reference model.py:53-54): fills qacc and the kinematic outputs */

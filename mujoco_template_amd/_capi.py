@@ -68,6 +68,12 @@ def load_library() -> ctypes.CDLL:
     L.mjb_get_counters.argtypes = [vp, vp]
     L.mjb_reset.argtypes = [vp, ci]
     L.mjb_forward.argtypes = [vp]
+    L.mjb_model_spec_source.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char_p, cl]
+    L.mjb_model_spec_source.restype = cl
+    L.mjb_spec_source.argtypes = [vp, ctypes.c_char_p, cl]
+    L.mjb_spec_source.restype = cl
+    L.mjb_spec_load.argtypes = [vp, ctypes.c_char_p, cl]
+    L.mjb_spec_unload.argtypes = [vp]
     L.mjb_inverse.argtypes = [vp]
     L.mjb_step.argtypes = [vp, ci]
     L.mjb_rollout.argtypes = [vp, ci, ci, cu, cu, cd, vp, vp, ci]
@@ -85,7 +91,7 @@ def load_library() -> ctypes.CDLL:
     L.mjb_debug_get.argtypes = [vp, ctypes.c_char_p, vp, cl]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
-                 "mjb_forward", "mjb_inverse", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
+                 "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get"):
         getattr(L, name).restype = ci
     _LIB = L
@@ -117,6 +123,58 @@ class _CudaArray:
 def _ids(seq: Sequence[int]):
     arr = np.ascontiguousarray(np.asarray(list(seq), dtype=np.int32))
     return arr, (arr.ctypes.data if arr.size else None)
+
+
+
+# ----------------------------------------------------------------------------------
+# per-model specialisation of the fp32 step kernel (include/mjbatch.h: mjb_*spec*)
+# ----------------------------------------------------------------------------------
+_WARNED_NO_SPEC = False
+_CSRC = os.path.join(_HERE, "csrc")
+_JIT_DIR = os.path.join(_HERE, "_jit")
+
+
+def _source_from(fn, *args) -> str:
+    n = fn(*args, None, 0)
+    if n < 0:
+        _check(-1)
+    buf = ctypes.create_string_buffer(int(n) + 1)
+    fn(*args, buf, int(n) + 1)
+    return buf.value.decode()
+
+
+def compile_spec(source: str, *, force: bool = False) -> str:
+    """Compile a specialised translation unit (``mjb_*spec_source``) to a gfx950 code object; returns its path.
+
+    Cached in-tree (``mujoco_template_amd/_jit/``, keyed by the source text and the kernel headers), so the objects built
+    by ``__graft_entry__.build()`` on a GPU-less machine travel with the tree.  hipcc cross-compiles without a GPU.
+    """
+    import hashlib
+    import shutil
+    import subprocess
+
+    h = hashlib.sha1(source.encode())
+    for f in ("mjb_types.hpp", "mjb_device.hpp", "mjb_kernels.hpp"):
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    key = h.hexdigest()[:20]
+    os.makedirs(_JIT_DIR, exist_ok=True)
+    out = os.path.join(_JIT_DIR, f"k_step_spec_{key}.hsaco")
+    if os.path.exists(out) and not force:
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise TemplateError("hipcc not found: cannot specialise the step kernel (the generic kernel remains available)")
+    src = os.path.join(_JIT_DIR, f"k_step_spec_{key}.hip")
+    with open(src, "w") as fh:
+        fh.write(source)
+    tmp = out + f".tmp{os.getpid()}"
+    cmd = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", "-I", _CSRC, "-o", tmp, src]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(tmp):
+        raise TemplateError("specialised kernel failed to compile:\n" + r.stderr[-2000:])
+    os.replace(tmp, out)
+    return out
 
 
 class ObsSpecHandle:
@@ -155,6 +213,10 @@ class DeviceModel:
     def set_solver(self, iterations: int, tolerance: float) -> None:
         _check(load_library().mjb_model_set_solver(self.ptr, int(iterations), float(tolerance)))
 
+    def spec_source(self, *, lanes: int = 0, nconmax: int = 0, nefcmax: int = 0) -> str:
+        """Translation unit of the specialised fp32 step kernel for these creation arguments (no GPU needed)."""
+        return _source_from(load_library().mjb_model_spec_source, self.ptr, MJB_F32, int(lanes), int(nconmax), int(nefcmax))
+
     def __del__(self):
         try:
             if self.ptr:
@@ -168,7 +230,7 @@ class BatchSim:
     """``batch`` replicas of one model resident on one GPU (handle of ``mjbData``)."""
 
     def __init__(self, model: DeviceModel, batch: int, *, dtype: str = "float32", lanes: int = 0, nconmax: int = 0,
-                 nefcmax: int = 0, device: int = 0, env0: int = 0):
+                 nefcmax: int = 0, device: int = 0, env0: int = 0, specialize: bool | None = None):
         L = load_library()
         if dtype not in ("float32", "float64"):
             raise ConfigError("dtype must be 'float32' or 'float64'")
@@ -183,6 +245,40 @@ class BatchSim:
         info = [ctypes.c_int() for _ in range(6)]
         _check(L.mjb_data_info(self.ptr, *[ctypes.byref(x) for x in info]))
         self.lanes, self.nconmax, self.nefcmax, self.lds_bytes_per_env = info[2].value, info[3].value, info[4].value, info[5].value
+        # per-model specialised fp32 kernel: on by default (MJB_SPECIALIZE=0 turns the default off); an explicit True raises
+        # if it cannot be built, the default falls back to the generic kernel with one warning
+        self.specialized = False
+        want = specialize if specialize is not None else (dtype == "float32" and os.environ.get("MJB_SPECIALIZE", "1") != "0")
+        if want:
+            try:
+                self.specialize()
+            except TemplateError as exc:
+                if specialize:
+                    raise
+                global _WARNED_NO_SPEC
+                if not _WARNED_NO_SPEC:
+                    import warnings
+
+                    warnings.warn(f"step kernel not specialised, using the generic kernel: {exc}", RuntimeWarning, stacklevel=2)
+                    _WARNED_NO_SPEC = True
+
+    # -- per-model specialised kernel ------------------------------------------------
+    def spec_source(self) -> str:
+        return _source_from(load_library().mjb_spec_source, self.ptr)
+
+    def specialize(self) -> None:
+        """Compile (or fetch from the in-tree cache) the step kernel specialised to this model's sizes and LDS layout and
+        use it for every later launch on this object.  float32 only; identical arithmetic to the generic kernel."""
+        if self.dtype != "float32":
+            raise ConfigError("only the float32 step kernel is specialised")
+        with open(compile_spec(self.spec_source()), "rb") as fh:
+            image = fh.read()
+        _check(load_library().mjb_spec_load(self.ptr, image, len(image)))
+        self.specialized = True
+
+    def unspecialize(self) -> None:
+        _check(load_library().mjb_spec_unload(self.ptr))
+        self.specialized = False
 
     # -- plumbing -----------------------------------------------------------------
     def set_stream(self, stream_handle: int) -> None:

@@ -81,6 +81,9 @@ struct mjbData {
   // device-side feedback controller gains (float and double copies): K [nu, 2nv], u0 [nu], q0 [nq], v0 [nv]
   float* fbf[4] = {nullptr, nullptr, nullptr, nullptr};
   double* fbd[4] = {nullptr, nullptr, nullptr, nullptr};
+  // per-model specialised fp32 step kernel (mjb_spec_load); null = generic kernel
+  hipModule_t spec_mod = nullptr;
+  hipFunction_t spec_fn = nullptr;
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   int* fd_valid = nullptr;
@@ -158,11 +161,71 @@ int refresh_options(mjbData* d) {
   return MJB_OK;
 }
 
+
+// Default caps on contacts / constraint rows held in LDS per environment (see mjb_data_create).
+void choose_caps(const HostModel& h, int dtype, int lanes, int nconmax, int nefcmax, int& nc_out, int& ne_out) {
+  int ne, nc;
+  if (nconmax > 0 || nefcmax > 0) {
+    nc = nconmax > 0 ? nconmax : (h.ncon_alloc < 32 ? h.ncon_alloc : 32);
+    ne = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 96 ? h.nefc_alloc : 96);
+  } else {
+    const size_t budget = (size_t)160 * 1024 / (dtype == MJB_F32 ? 8 : 4);
+    ne = h.nefc_alloc < 96 ? h.nefc_alloc : 96; nc = 0;
+    if (h.nefc_alloc <= 96 && h.ncon_alloc <= 32) {
+      // the model's own worst case (every candidate pair in contact, every limit active) is small: hold all of it, nothing
+      // can ever be dropped (drone2: 20 contacts / 80+ rows when it lands flat); occupancy is not traded against that
+      ne = h.nefc_alloc; nc = h.ncon_alloc;
+    } else for (;; ne -= 8) {
+      nc = ne * 3 / 8; if (nc < 8) nc = 8; if (nc > h.ncon_alloc) nc = h.ncon_alloc;
+      Lay t = make_layout(h, nc > 0 ? nc : 1, ne > 0 ? ne : 1, dtype == MJB_F32 ? sizeof(float) : sizeof(double));
+      if ((size_t)(64 / lanes) * (size_t)t.bytes <= budget || ne <= 32) break;
+    }
+  }
+  if (nc < 1) nc = 1;
+  if (ne < 1) ne = 1;
+  nc_out = nc; ne_out = ne;
+}
+int auto_lanes(const HostModel& h, int lanes) { return lanes == 0 ? (h.nv <= 4 ? 8 : (h.nv <= 16 ? 16 : 64)) : lanes; }
+
+// Translation unit of the specialised fp32 step kernel of one compiled model: the structural sizes of DevModel (never the
+// run-time options: disableactuator, iterations, tolerance) and every LDS layout offset become __builtin_assume()s.
+std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, int nefc_max) {
+  std::string s = "// generated by mjb_model_spec_source(): size- and layout-specialised k_step<float, float, G> of ONE compiled model\n";
+  s += "#define MJB_SPEC_KERNEL 1\n#define MJB_SPEC_G " + std::to_string(G) + "\n#define MJB_SPEC_ASSUME(m)";
+  auto A = [&](const char* obj, const char* f, long v) { s += std::string(" __builtin_assume((") + obj + ")." + f + " == " + std::to_string(v) + ");"; };
+#define SM(f, v) A("m", #f, (long)(v))
+  SM(nq, h.nq); SM(nv, h.nv); SM(nu, h.nu); SM(nbody, h.nbody); SM(njnt, h.njnt); SM(ngeom, h.ngeom); SM(nsite, h.nsite);
+  SM(ntendon, h.ntendon); SM(nwrap, h.nwrap); SM(nsensor, h.nsensor); SM(nsensordata, h.nsensordata); SM(nkey, h.nkey); SM(npair, h.npair);
+  SM(nlevel, h.nlevel); SM(integrator, h.integrator); SM(has_damping, h.has_damping); SM(has_fluid, h.has_fluid); SM(has_accel, h.has_accel);
+  SM(nvp, h.nvp); SM(nvshift, h.nvshift); SM(ncon_max, ncon_max); SM(nefc_max, nefc_max); SM(nsiteact, h.siteact.size()); SM(nmpair, h.mpair.size());
+  SM(nround, h.nround); SM(nround_inner, h.nround_inner);
+#undef SM
+  s += "\n#define MJB_SPEC_ASSUME_LAY(L)";
+#define SL(f) A("L", #f, (long)L.f)
+  SL(qpos); SL(qvel); SL(ctrl); SL(qacc); SL(qacc_ws); SL(qacc_smooth); SL(qfrc_bias); SL(qfrc_passive); SL(qfrc_actuator); SL(qfrc_smooth);
+  SL(qfrc_constraint); SL(xpos); SL(xquat); SL(xmat); SL(xipos); SL(ximat); SL(xanchor); SL(xaxis); SL(geom_xpos); SL(geom_xmat); SL(site_xpos);
+  SL(site_xmat); SL(subtree_com); SL(cinert); SL(crb); SL(cdof); SL(cdof_dot); SL(cvel); SL(cacc); SL(cfrc); SL(dofbuf); SL(bfrc); SL(M); SL(W);
+  SL(ten_length); SL(ten_J); SL(act_force); SL(sens); SL(con); SL(efc_J); SL(efc_pos); SL(efc_D); SL(efc_aref); SL(efc_jar); SL(efc_jv);
+  SL(efc_force); SL(efc_KBI); SL(Ma); SL(grad); SL(search); SL(Mv); SL(tmp); SL(cholcol); SL(rk); SL(nT); SL(i_efc_type); SL(i_efc_id);
+  SL(i_con_pair); SL(i_scal); SL(nI); SL(bytes);
+#undef SL
+  s += "\n#include \"mjb_kernels.hpp\"\n";
+  return s;
+}
+
 int launch(mjbData* d, const StepArgs& a, const ObsSpecDev& obs, void* obs_out, bool debug) {
   int rc = refresh_options(d);
   if (rc != MJB_OK) return rc;
   hipError_t e;
-  if (d->dtype == MJB_F32) {
+  if (d->dtype == MJB_F32 && d->spec_fn) {               // per-model specialised kernel: same arguments, same grid
+    DevDebug<float> dbgarg; std::memset(&dbgarg, 0, sizeof(dbgarg));
+    if (debug) dbgarg = d->dbgf;
+    const DevModel<float>* mg = d->mf_dev; const Lay* lg = d->Lf_dev;
+    DevData<float> dv = d->df; StepArgs av = a; ObsSpecDev ov = obs; float* oo = (float*)obs_out;
+    void* args[] = {(void*)&mg, (void*)&lg, (void*)&dv, (void*)&dbgarg, (void*)&av, (void*)&ov, (void*)&oo};
+    const int epb = 64 / d->G;
+    e = hipModuleLaunchKernel(d->spec_fn, (unsigned)((d->batch + epb - 1) / epb), 1, 1, 64, 1, 1, (unsigned)((size_t)epb * d->Lf.bytes), d->stream, args, nullptr);
+  } else if (d->dtype == MJB_F32) {
     DevDebug<float> none; std::memset(&none, 0, sizeof(none));
     e = launch_step<float, float>(d->G, d->mf_dev, d->Lf_dev, d->Lf, d->df, debug ? d->dbgf : none, a, obs, (float*)obs_out, d->stream);
   } else {
@@ -230,7 +293,7 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
   if (device < 0 || device >= ndev) return fail(MJB_ERR_ARG, "device index out of range");
   HIPCHK(hipSetDevice(device));
   const HostModel& h = m->h;
-  if (lanes == 0) lanes = h.nv <= 4 ? 8 : (h.nv <= 16 ? 16 : 64);
+  lanes = auto_lanes(h, lanes);
   if (lanes != 8 && lanes != 16 && lanes != 64) return fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64");
   mjbData* d = new mjbData();
   d->model = m; d->batch = batch; d->dtype = dtype; d->G = lanes; d->device = device; d->env0 = env0; d->stream = nullptr;
@@ -238,25 +301,7 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
   // model's own worst case when that is small (<= 96 rows, <= 32 contacts); otherwise the largest (rows <= 96, contacts =
   // 3/8 rows) that still lets 8 fp32 (4 fp64) wavefronts share one CU's 160 KiB — the occupancy step that matters most
   // for throughput (profiles/).  Overflow drops rows and is COUNTED.
-  if (nconmax > 0 || nefcmax > 0) {
-    d->ncon_max = nconmax > 0 ? nconmax : (h.ncon_alloc < 32 ? h.ncon_alloc : 32);
-    d->nefc_max = nefcmax > 0 ? nefcmax : (h.nefc_alloc < 96 ? h.nefc_alloc : 96);
-  } else {
-    const size_t budget = (size_t)160 * 1024 / (dtype == MJB_F32 ? 8 : 4);
-    int ne = h.nefc_alloc < 96 ? h.nefc_alloc : 96, nc = 0;
-    if (h.nefc_alloc <= 96 && h.ncon_alloc <= 32) {
-      // the model's own worst case (every candidate pair in contact, every limit active) is small: hold all of it, nothing
-      // can ever be dropped (drone2: 20 contacts / 80+ rows when it lands flat); occupancy is not traded against that
-      ne = h.nefc_alloc; nc = h.ncon_alloc;
-    } else for (;; ne -= 8) {
-      nc = ne * 3 / 8; if (nc < 8) nc = 8; if (nc > h.ncon_alloc) nc = h.ncon_alloc;
-      Lay t = make_layout(h, nc > 0 ? nc : 1, ne > 0 ? ne : 1, dtype == MJB_F32 ? sizeof(float) : sizeof(double));
-      if ((size_t)(64 / lanes) * (size_t)t.bytes <= budget || ne <= 32) break;
-    }
-    d->nefc_max = ne; d->ncon_max = nc;
-  }
-  if (d->ncon_max < 1) d->ncon_max = 1;
-  if (d->nefc_max < 1) d->nefc_max = 1;
+  choose_caps(h, dtype, lanes, nconmax, nefcmax, d->ncon_max, d->nefc_max);
   fill_dev_model<float>(h, d->alloc, d->ncon_max, d->nefc_max, d->mf);
   fill_dev_model<double>(h, d->alloc, d->ncon_max, d->nefc_max, d->md);
   if (!d->alloc.ok) { mjb_data_free(d); return fail(MJB_ERR_DEVICE, "device allocation of the model failed"); }
@@ -288,6 +333,7 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
 }
 
 void mjb_data_free(mjbData* d) {
+  if (d && d->spec_mod) { hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; }
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : d->owned) (void)hipFree(p);
@@ -382,6 +428,48 @@ static StepArgs make_args(mjbData* d, int nstep, int ctrl_mode, unsigned seed, u
   a.nstep = nstep; a.ctrl_mode = ctrl_mode; a.seed = seed; a.step0 = step0; a.env0 = (unsigned)d->env0;
   a.ctrl_scale = scale; a.dt = d->model->h.timestep; a.mode = mode; a.write_kin = 1; a.obs_every = 0;
   return a;
+}
+
+long mjb_model_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int nefcmax, char* buf, long cap) {
+  if (!m) { fail(MJB_ERR_ARG, "model is NULL"); return -1; }
+  if (dtype != MJB_F32) { fail(MJB_ERR_ARG, "only the float32 step kernel is specialised"); return -1; }
+  const HostModel& h = m->h;
+  lanes = auto_lanes(h, lanes);
+  if (lanes != 8 && lanes != 16 && lanes != 64) { fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64"); return -1; }
+  int nc, ne;
+  choose_caps(h, dtype, lanes, nconmax, nefcmax, nc, ne);
+  const std::string src = spec_source(h, make_layout(h, nc, ne, sizeof(float)), lanes, nc, ne);
+  if (buf && cap > (long)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+  return (long)src.size();
+}
+
+long mjb_spec_source(mjbData* d, char* buf, long cap) {
+  if (!d) { fail(MJB_ERR_ARG, "data is NULL"); return -1; }
+  if (d->dtype != MJB_F32) { fail(MJB_ERR_ARG, "only the float32 step kernel is specialised"); return -1; }
+  const std::string src = spec_source(d->model->h, d->Lf, d->G, d->ncon_max, d->nefc_max);
+  if (buf && cap > (long)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+  return (long)src.size();
+}
+
+int mjb_spec_load(mjbData* d, const void* image, long nbytes) {
+  if (!d || !image || nbytes <= 0) return fail(MJB_ERR_ARG, "NULL argument");
+  if (d->dtype != MJB_F32) return fail(MJB_ERR_ARG, "only the float32 step kernel is specialised");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  if (d->spec_mod) { hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; }
+  hipModule_t mod; hipFunction_t fn;
+  hipError_t e = hipModuleLoadData(&mod, image);
+  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+  e = hipModuleGetFunction(&fn, mod, "mjb_k_step_spec");
+  if (e != hipSuccess) { hipModuleUnload(mod); return fail(MJB_ERR_DEVICE, "code object has no mjb_k_step_spec kernel"); }
+  d->spec_mod = mod; d->spec_fn = fn;
+  return MJB_OK;
+}
+
+int mjb_spec_unload(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (d->spec_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; }
+  return MJB_OK;
 }
 
 int mjb_forward(mjbData* d) {

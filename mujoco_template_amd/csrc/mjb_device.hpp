@@ -456,13 +456,23 @@ MJB_DEV void tile_factor(MRef m, const T* M, T* W, T* dinv, T* col, const T* J, 
 // Re-materialise the model / layout pointers at the start of every phase: the (invariant) loads through
 // them then stay local to the phase instead of being hoisted to the kernel entry, where ~190 live SGPRs
 // were spilled to VGPR lanes (17 % of the instruction stream was v_readlane / v_writelane).
+// Per-model specialisation (mjb_spec_source / mjb_spec_load): the generated translation unit defines these two macros as
+// lists of __builtin_assume(field == value) over the structural sizes of the model and the LDS layout offsets; sizes,
+// trip counts and offsets then fold to constants in every phase (same source, same arithmetic).  Empty in the generic build.
+#ifndef MJB_SPEC_ASSUME
+#define MJB_SPEC_ASSUME(m)
+#endif
+#ifndef MJB_SPEC_ASSUME_LAY
+#define MJB_SPEC_ASSUME_LAY(L)
+#endif
 #ifdef MJB_HOST_EMU
 #define MJB_ENV(c) ModelRef<T> m = *(c).mp; LayRef L = *(c).lp
 #else
 #define MJB_ENV(c)                                     \
   auto mp_ = (c).mp; auto lp_ = (c).lp;                \
   asm volatile("" : "+s"(mp_), "+s"(lp_));             \
-  ModelRef<T> m = *mp_; LayRef L = *lp_
+  ModelRef<T> m = *mp_; LayRef L = *lp_;               \
+  MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
 #endif
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
 #define MJB_STAMP(c, k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).pacc[k] += t_ - (c).pt; (c).pt = t_; } while (0)
@@ -2192,6 +2202,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
                      const ObsSpecDev& obs, TS* obs_out, T* w, int* wi, int env, int lane) {
   Ctx<T> c(mp, lp, w, wi, lane);
   ModelRef<T> m = *mp; LayRef L = *lp;
+  MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
   const int nq = m.nq, nv = m.nv, nu = m.nu;
   for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
   for (int i = lane; i < nv; i += G) {

@@ -90,11 +90,11 @@ class Env:
                       reward_fn=None, done_fn=None, info_fn=None, enabled_groups: Iterable[int] | None = None,
                       control_decimation: int = 1, auto_reset: bool = True, keyframe: int | str | None = None,
                       batch: int = 1, dtype: str = "float32", device: int = 0, lanes: int = 0, nconmax: int = 0,
-                      nefcmax: int = 0, env0: int = 0) -> "Env":
+                      nefcmax: int = 0, env0: int = 0, specialize: bool | None = None) -> "Env":
         if obs_spec is None:
             obs_spec = ObservationSpec(include_sensordata=False)
         handle = ModelHandle.from_xml_path(xml_path, batch=batch, dtype=dtype, device=device, lanes=lanes, nconmax=nconmax,
-                                           nefcmax=nefcmax, env0=env0)
+                                           nefcmax=nefcmax, env0=env0, specialize=specialize)
         if controller is not None and hasattr(controller, "env0"):
             controller.env0 = env0
         env = cls(handle, obs_spec=obs_spec, controller=controller, reward_fn=reward_fn, done_fn=done_fn, info_fn=info_fn,

@@ -154,7 +154,7 @@ _SHAPE3 = {"xpos": 3, "xquat": 4, "xipos": 3, "site_xpos": 3, "geom_xpos": 3, "s
 
 class MjData:
     def __init__(self, model: MjModel, batch: int = 1, *, dtype: str = "float32", device: int = 0, lanes: int = 0,
-                 nconmax: int = 0, nefcmax: int = 0, env0: int = 0):
+                 nconmax: int = 0, nefcmax: int = 0, env0: int = 0, specialize: bool | None = None):
         if not isinstance(model, MjModel):
             raise TypeError("MjData(model): model must be an MjModel")
         if batch < 1:
@@ -162,7 +162,7 @@ class MjData:
         self.model = model
         self.batch = int(batch)
         self._sim = BatchSim(model._device_model(), self.batch, dtype=dtype, lanes=lanes, nconmax=nconmax, nefcmax=nefcmax,
-                             device=device, env0=env0)
+                             device=device, env0=env0, specialize=specialize)
         self._mirror: dict[str, np.ndarray] = {}
         self._shadow: dict[str, np.ndarray] = {}
         self._dev_newer: set[str] = set(_STATE) | set(_DERIVED) | {"time"}
