@@ -158,19 +158,40 @@ def compile_spec(source: str, *, force: bool = False) -> str:
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(fh.read())
     key = h.hexdigest()[:20]
-    os.makedirs(_JIT_DIR, exist_ok=True)
     out = os.path.join(_JIT_DIR, f"k_step_spec_{key}.hsaco")
     if os.path.exists(out) and not force:
         return out
+    jit_dir = _JIT_DIR
+    try:
+        os.makedirs(jit_dir, exist_ok=True)
+        if not os.access(jit_dir, os.W_OK):
+            raise OSError("not writable")
+    except OSError:                                            # read-only install: per-user cache under the temp directory
+        import tempfile
+
+        jit_dir = os.path.join(tempfile.gettempdir(), f"mjb_jit_{os.getuid()}")
+        try:
+            os.makedirs(jit_dir, exist_ok=True)
+        except OSError as exc:
+            raise TemplateError(f"no writable cache directory for the specialised kernel: {exc}") from exc
+        out = os.path.join(jit_dir, f"k_step_spec_{key}.hsaco")
+        if os.path.exists(out) and not force:
+            return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise TemplateError("hipcc not found: cannot specialise the step kernel (the generic kernel remains available)")
-    src = os.path.join(_JIT_DIR, f"k_step_spec_{key}.hip")
-    with open(src, "w") as fh:
-        fh.write(source)
+    src = os.path.join(jit_dir, f"k_step_spec_{key}.hip")
+    try:
+        with open(src, "w") as fh:
+            fh.write(source)
+    except OSError as exc:
+        raise TemplateError(f"cannot write the specialised kernel source: {exc}") from exc
     tmp = out + f".tmp{os.getpid()}"
     cmd = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", "-I", _CSRC, "-o", tmp, src]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    except (OSError, subprocess.SubprocessError) as exc:
+        raise TemplateError(f"hipcc could not be run: {exc}") from exc
     if r.returncode != 0 or not os.path.exists(tmp):
         raise TemplateError("specialised kernel failed to compile:\n" + r.stderr[-2000:])
     os.replace(tmp, out)
