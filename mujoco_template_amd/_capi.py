@@ -153,7 +153,8 @@ def compile_spec(source: str, *, force: bool = False) -> str:
     import shutil
     import subprocess
 
-    h = hashlib.sha1(source.encode())
+    extra = os.environ.get("MJB_SPEC_FLAGS", "").split()        # experiments, e.g. -DMJB_WPS=3 (register budget for 3 waves/SIMD)
+    h = hashlib.sha1((source + " ".join(extra)).encode())
     for f in ("mjb_types.hpp", "mjb_device.hpp", "mjb_kernels.hpp"):
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -187,7 +188,7 @@ def compile_spec(source: str, *, force: bool = False) -> str:
     except OSError as exc:
         raise TemplateError(f"cannot write the specialised kernel source: {exc}") from exc
     tmp = out + f".tmp{os.getpid()}"
-    cmd = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", "-I", _CSRC, "-o", tmp, src]
+    cmd = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", *extra, "-I", _CSRC, "-o", tmp, src]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     except (OSError, subprocess.SubprocessError) as exc:
