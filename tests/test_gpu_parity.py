@@ -454,6 +454,10 @@ def test_specialised_kernel_is_bitwise_identical_to_the_generic_one(world, name,
     import mujoco_template_amd._capi as capi
 
     cm, om, dm = world(name)
+    try:
+        capi.compile_spec(dm.spec_source())
+    except capi.TemplateError as exc:                          # no hipcc on this box: the product falls back to the generic kernel
+        pytest.skip(f"specialised kernel cannot be built here: {exc}")
     B = 512
     res = {}
     for spec in (False, None):
