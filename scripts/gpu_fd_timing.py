@@ -1,0 +1,18 @@
+"""Timing of the batched finite-difference linearisation (mjd_transitionFD, float64 on device) and Jacobians."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mujoco_template_amd.mjcf import compile_xml_path
+from mujoco_template_amd._capi import BatchSim, DeviceModel, CTRL_RANDOM
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for name, B, scale in (("cartpole", 512, 0.01), ("cartpole", 4096, 0.01), ("drone2/scene", 2048, 0.3), ("humanoid", 64, 1.0), ("humanoid", 512, 1.0)):
+    cm = compile_xml_path(os.path.join(ROOT, f"models/{name}.xml"))
+    sim = BatchSim(DeviceModel(cm), B, dtype="float64")
+    sim.rollout(100, CTRL_RANDOM, seed=1, ctrl_scale=scale); sim.sync()
+    sim.transition_fd(1e-6, True)
+    t = time.time(); n = 5
+    for _ in range(n):
+        A, Bm = sim.transition_fd(1e-6, True)
+    dt = (time.time() - t) / n
+    ncol = 1 + 2 * (2 * cm.nv + cm.nu)
+    print(f"{name:14s} B={B:5d}: transition_fd {dt*1e3:8.2f} ms per call = {B/dt:.3e} linearisations/s = {B*ncol/dt:.3e} perturbed env-steps/s (float64, {ncol} columns), A {A.shape} B {Bm.shape}", flush=True)
