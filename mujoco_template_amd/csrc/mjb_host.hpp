@@ -228,6 +228,28 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   m.sensor_type = Iq("sensor_type"); m.sensor_objid = Iq("sensor_objid"); m.sensor_adr = Iq("sensor_adr");
   m.pair_geom1 = Iq("pair_geom1"); m.pair_geom2 = Iq("pair_geom2"); m.pair_condim = Iq("pair_condim");
   m.pair_friction = F("pair_friction"); m.pair_solref = F("pair_solref"); m.pair_solimp = F("pair_solimp"); m.pair_margin = F("pair_margin"); m.pair_gap = F("pair_gap");
+  {
+    // bounding radius of every geom about its centre (conservative), folded with the pair margin for the broad phase
+    const auto& gt = h.I("geom_type"); const auto& gs = h.D("geom_size");
+    const auto& g1 = h.I("pair_geom1"); const auto& g2 = h.I("pair_geom2"); const auto& pm = h.D("pair_margin");
+    auto rb = [&](int g) -> double {
+      const double a = gs[3 * g], b = gs[3 * g + 1], c = gs[3 * g + 2];
+      switch (gt[g]) {
+        case G_SPHERE: return a;
+        case G_CAPSULE: return a + b;
+        case G_ELLIPSOID: return std::max(a, std::max(b, c));
+        case G_BOX: return std::sqrt(a * a + b * b + c * c);
+        default: return 0.0;                                   // plane: handled through the signed distance
+      }
+    };
+    std::vector<T> cull((size_t)h.npair);
+    for (int p = 0; p < h.npair; p++) {
+      const bool plane = gt[g1[p]] == G_PLANE;
+      const double r = (plane ? 0.0 : rb(g1[p])) + rb(g2[p]) + pm[p];
+      cull[p] = (T)(plane ? -std::max(r, 1e-30) : r);
+    }
+    m.pair_cull = (FP)alloc.putf(cull);
+  }
   m.key_qpos = F("key_qpos"); m.key_qvel = F("key_qvel"); m.key_ctrl = F("key_ctrl"); m.key_time = F("key_time");
 }
 

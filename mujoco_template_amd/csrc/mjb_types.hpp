@@ -65,6 +65,7 @@ struct DevModel {
   // collision pairs
   IP pair_geom1, pair_geom2, pair_condim;
   FP pair_friction, pair_solref, pair_solimp, pair_margin, pair_gap;
+  FP pair_cull;      // broad phase: r1 + r2 + margin (bounding radii); NEGATED when geom1 is a plane (then r2 + margin)
   // keyframes
   FP key_qpos, key_qvel, key_ctrl, key_time;
 };
