@@ -198,7 +198,7 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
   SM(ntendon, h.ntendon); SM(nwrap, h.nwrap); SM(nsensor, h.nsensor); SM(nsensordata, h.nsensordata); SM(nkey, h.nkey); SM(npair, h.npair);
   SM(nlevel, h.nlevel); SM(integrator, h.integrator); SM(has_damping, h.has_damping); SM(has_fluid, h.has_fluid); SM(has_accel, h.has_accel);
   SM(nvp, h.nvp); SM(nvshift, h.nvshift); SM(ncon_max, ncon_max); SM(nefc_max, nefc_max); SM(nsiteact, h.siteact.size()); SM(nmpair, h.mpair.size());
-  SM(nround, h.nround); SM(nround_inner, h.nround_inner);
+  SM(nround, h.nround); SM(nround_inner, h.nround_inner); SM(max_nsub, h.max_nsub); SM(dfs_ok, h.dfs_ok);
 #undef SM
   s += "\n#define MJB_SPEC_ASSUME_LAY(L)";
 #define SL(f) A("L", #f, (long)L.f)

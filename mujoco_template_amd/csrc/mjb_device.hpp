@@ -867,7 +867,7 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
 // A1 kinematics: tree levels in order, bodies of a level across lanes
 // ---------------------------------------------------------------------------
 // arr[b] += arr[parent] down the tree (velocities, bias accelerations): depth and parent of the lane's body in registers
-template <typename T, int G, int NC> MJB_DEV void tree_forward_sum(Ctx<T>& c, T* arr) {
+template <typename T, int G, int NC> MJB_DEV void tree_forward_sum_levels(Ctx<T>& c, T* arr) {
   MJB_ENV(c); const int lane = c.lane;
   const int b0 = 1 + lane;
   int dep0 = -1, par0 = 0;
@@ -891,7 +891,7 @@ template <typename T, int G, int NC> MJB_DEV void tree_forward_sum(Ctx<T>& c, T*
 // Bodies are scheduled in "rounds" (host: deepest level first, one sibling rank per round) so that no two bodies of a
 // round share a parent and every body is complete before it is added.  The lane's body, round and parent stay in
 // registers: one round = LDS read-add-write, no index tables on the critical path.
-template <typename T, int G, int NC> MJB_DEV void tree_backward_sum(Ctx<T>& c, T* arr, int nrounds) {
+template <typename T, int G, int NC> MJB_DEV void tree_backward_sum_rounds(Ctx<T>& c, T* arr, int nrounds) {
   MJB_ENV(c); const int lane = c.lane;
   const int b0 = 1 + lane;
   int rd0 = -1, p0 = 0;
@@ -915,6 +915,71 @@ template <typename T, int G, int NC> MJB_DEV void tree_backward_sum(Ctx<T>& c, T
     }
     gsync<G>();
   }
+}
+
+// Flat forms of the two tree sums: ONE read phase, a sync, one write phase - instead of a dependent LDS round trip per tree
+// level / per round.  Work item = (body, component), all 64 lanes busy.
+//  * ancestor sum  x[b] += sum of x over the proper ancestors of b (the world body excluded): host table body_anc
+//    [nbody, nlevel] (parent, grandparent, ...), all table entries and all LDS reads of an item are independent loads;
+//  * subtree sum   x[b] += sum of x over the descendants of b: with the bodies in depth-first order (checked on the host:
+//    dfs_ok) the descendants are the id range (b, b + nsub[b]], read with loads masked beyond nsub.
+// Every item reads ORIGINAL values (the sync separates all reads from all writes), so the sums are formed in place.
+// Up to MJB_TREE_PASSES * G items stay in registers; larger models / non-DFS body orders use the level / round loops.
+#define MJB_TREE_PASSES 4
+template <typename T, int G, int NC> MJB_DEV void tree_forward_sum(Ctx<T>& c, T* arr) {
+  MJB_ENV(c); const int lane = c.lane;
+  const int nitem = m.nbody * NC, nl = m.nlevel;
+  if (nitem > MJB_TREE_PASSES * G) { tree_forward_sum_levels<T, G, NC>(c, arr); return; }
+  T s[MJB_TREE_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < MJB_TREE_PASSES; ps++) {
+    const int e = lane + ps * G;
+    s[ps] = 0;
+    if (e < nitem) {
+      const int b = e / NC, k = e - b * NC;
+      const int na = b > 0 ? m.body_depth[b] - 1 : 0;
+      T acc = arr[e];
+      for (int u = 0; u < nl - 1; u++) {
+        const int a = m.body_anc[b * nl + u];
+        T v = arr[NC * a + k];
+        acc += u < na ? v : (T)0;
+      }
+      s[ps] = acc;
+    }
+  }
+  gsync<G>();
+#pragma unroll
+  for (int ps = 0; ps < MJB_TREE_PASSES; ps++) { const int e = lane + ps * G; if (e < nitem) arr[e] = s[ps]; }
+  gsync<G>();
+}
+template <typename T, int G, int NC> MJB_DEV void tree_backward_sum(Ctx<T>& c, T* arr, int nrounds, int first_body) {
+  MJB_ENV(c); const int lane = c.lane;
+  const int nitem = m.nbody * NC, mx = m.max_nsub;
+  if (!m.dfs_ok || nitem > MJB_TREE_PASSES * G) { tree_backward_sum_rounds<T, G, NC>(c, arr, nrounds); return; }
+  T s[MJB_TREE_PASSES];
+#pragma unroll
+  for (int ps = 0; ps < MJB_TREE_PASSES; ps++) {
+    const int e = lane + ps * G;
+    s[ps] = 0;
+    if (e < nitem) {
+      const int b = e / NC;
+      const int n = b >= first_body ? m.body_nsub[b] : 0;
+      const T* base = arr + e;
+      T acc = base[0];
+      for (int d0 = 0; d0 < mx; d0 += 4) {                      // four masked loads in flight per step
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int dd = d0 + u + 1; v[u] = base[NC * (dd <= n ? dd : n)]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += d0 + u + 1 <= n ? v[u] : (T)0;
+      }
+      s[ps] = acc;
+    }
+  }
+  gsync<G>();
+#pragma unroll
+  for (int ps = 0; ps < MJB_TREE_PASSES; ps++) { const int e = lane + ps * G; if (e < nitem) arr[e] = s[ps]; }
+  gsync<G>();
 }
 
 // rotate v by the unit quaternion q (through the rotation matrix, like the per-body frames)
@@ -1079,7 +1144,7 @@ template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
     for (int k = 0; k < 3; k++) sc[3 * b + k] = ms * xipos[3 * b + k];
   }
   gsync<G>();
-  tree_backward_sum<T, G, 3>(c, sc, m.nround);              // includes the world body's subtree (everything)
+  tree_backward_sum<T, G, 3>(c, sc, m.nround, 0);           // includes the world body's subtree (everything)
   for (int b = lane; b < m.nbody; b += G) {
     T sm = m.body_subtreemass[b];
     if (sm < Num<T>::minval()) { sc[3 * b] = xipos[3 * b]; sc[3 * b + 1] = xipos[3 * b + 1]; sc[3 * b + 2] = xipos[3 * b + 2]; }
@@ -1165,7 +1230,7 @@ template <typename T, int G> MJB_DEV void crb_factor(Ctx<T>& c) {
   T *crb = w + L.crb, *cin = w + L.cinert, *cdof = w + L.cdof, *buf = w + L.dofbuf, *M = w + L.M, *W = w + L.W;
   for (int i = lane; i < 10 * m.nbody; i += G) crb[i] = cin[i];
   gsync<G>();
-  tree_backward_sum<T, G, 10>(c, crb, m.nround_inner);
+  tree_backward_sum<T, G, 10>(c, crb, m.nround_inner, 1);
   for (int i = lane; i < nv; i += G) {
     T in[10], v[6], r[6];
     int b = m.dof_bodyid[i];
@@ -1663,7 +1728,7 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
     for (int k = 0; k < 6; k++) cfrc[6 * b + k] = f[k] + t2[k];
   }
   gsync<G>();
-  tree_backward_sum<T, G, 6>(c, cfrc, m.nround_inner);
+  tree_backward_sum<T, G, 6>(c, cfrc, m.nround_inner, 1);
   // fluid forces per body (inertia-box model) into bfrc = [torque; force] at xipos
   T* bfrc = w + L.bfrc;
   if (m.has_fluid) {

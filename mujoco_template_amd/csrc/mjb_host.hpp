@@ -49,7 +49,8 @@ struct HostModel {
   std::vector<std::pair<std::string, std::vector<double>>> fd;
   std::vector<std::pair<std::string, std::vector<int>>> id;
   std::vector<int> level_adr, level_body, child_adr, child_id, tri_tab, dofact_adr, dofact_act, siteact, mpair, body_round;
-  int nround = 0, nround_inner = 0;
+  int nround = 0, nround_inner = 0, max_nsub = 0, dfs_ok = 0;
+  std::vector<int> body_nsub, body_anc;
   std::vector<unsigned long long> body_dofmask, dof_ancmask;
 
   const std::vector<double>& D(const char* k) const {
@@ -130,6 +131,29 @@ struct HostModel {
       body_round.assign(nbody, -1);
       for (int b = 1; b < nbody; b++) body_round[b] = base[depth[b]] + rank[b];
     }
+    // flat tree sums: descendants count (and whether the descendants of every body are the id range right behind it, i.e.
+    // the bodies are in depth-first order) and the table of proper ancestors (parent, grandparent, ...; world excluded)
+    {
+      body_nsub.assign(nbody, 0);
+      for (int b = nbody - 1; b >= 1; b--) body_nsub[parent[b]] += body_nsub[b] + 1;
+      dfs_ok = 1; max_nsub = 0;
+      for (int b = 0; b < nbody; b++) {
+        if (b >= 1 && body_nsub[b] > max_nsub) max_nsub = body_nsub[b];
+        for (int d = b + 1; d <= b + body_nsub[b] && d < nbody; d++) {          // every id in the range must descend from b
+          int a = d; while (a != b && a != 0) a = parent[a];
+          if (a != b) dfs_ok = 0;
+        }
+        if (b + body_nsub[b] >= nbody) dfs_ok = 0;
+      }
+      if (body_nsub[0] > max_nsub) max_nsub = body_nsub[0];
+      const int nl = nlevel > 0 ? nlevel : 1;
+      body_anc.assign((size_t)nbody * nl, 0);
+      for (int b = 0; b < nbody; b++) {
+        int a = b, u = 0;
+        for (; u < nl; u++) { if (a == 0 || parent[a] == 0) break; a = parent[a]; body_anc[(size_t)b * nl + u] = a; }
+        for (; u < nl; u++) body_anc[(size_t)b * nl + u] = b;                   // padding (masked on the device)
+      }
+    }
     child_adr.assign(nbody + 1, 0);
     child_id.clear();
     for (int b = 0; b < nbody; b++) {
@@ -204,7 +228,8 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
     return (FP)alloc.putf(tv);
   };
   auto Iq = [&](const char* k) -> IP { return (IP)alloc.puti(h.I(k)); };
-  m.body_parentid = Iq("body_parentid"); m.body_depth = Iq("body_depth"); m.body_round = (IP)alloc.puti(h.body_round); m.nround = h.nround; m.nround_inner = h.nround_inner; m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
+  m.body_parentid = Iq("body_parentid"); m.body_depth = Iq("body_depth"); m.body_round = (IP)alloc.puti(h.body_round); m.nround = h.nround; m.nround_inner = h.nround_inner;
+  m.body_nsub = (IP)alloc.puti(h.body_nsub); m.body_anc = (IP)alloc.puti(h.body_anc); m.max_nsub = h.max_nsub; m.dfs_ok = h.dfs_ok; m.body_rootid = Iq("body_rootid"); m.body_jntadr = Iq("body_jntadr"); m.body_jntnum = Iq("body_jntnum");
   m.body_dofadr = Iq("body_dofadr"); m.body_dofnum = Iq("body_dofnum");
   m.level_adr = (IP)alloc.puti(h.level_adr); m.level_body = (IP)alloc.puti(h.level_body); m.child_adr = (IP)alloc.puti(h.child_adr); m.child_id = (IP)alloc.puti(h.child_id); m.tri_tab = (IP)alloc.puti(h.tri_tab);
   m.dofact_adr = (IP)alloc.puti(h.dofact_adr); m.dofact_act = (IP)alloc.puti(h.dofact_act); m.siteact = (IP)alloc.puti(h.siteact); m.mpair = (IP)alloc.puti(h.mpair);

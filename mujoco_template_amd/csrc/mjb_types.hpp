@@ -36,10 +36,10 @@ struct DevModel {
   typedef const unsigned long long MJB_CONST* UP;    // 64-bit dof mask table
   int nq, nv, nu, nbody, njnt, ngeom, nsite, ntendon, nwrap, nsensor, nsensordata, nkey, npair;
   int nlevel, integrator, disableactuator, iterations, has_damping, has_fluid, has_accel, nvp, nvshift;
-  int ncon_max, nefc_max, nsiteact, nmpair, nround, nround_inner;
+  int ncon_max, nefc_max, nsiteact, nmpair, nround, nround_inner, max_nsub, dfs_ok;
   T timestep, gravity[3], density, viscosity, tolerance, meaninertia;
   // kinematic tree
-  IP body_parentid, body_rootid, body_jntadr, body_jntnum, body_dofadr, body_dofnum, body_depth, body_round;
+  IP body_parentid, body_rootid, body_jntadr, body_jntnum, body_dofadr, body_dofnum, body_depth, body_round, body_nsub, body_anc;
   IP level_adr, level_body, child_adr, child_id, tri_tab;
   IP dofact_adr, dofact_act, siteact, mpair;   // joint-transmission actuators per dof (CSR), site-transmission actuators, (i<<8|j) ancestor dof pairs of M
   FP body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_subtreemass, body_invweight0;
