@@ -605,6 +605,50 @@ MJB_DEV void mfma_back_chain8(float (&lrow)[8], int blk, int n, int c_, float my
   for (int t = 7; t >= 0; t--) rs -= lrow[t] * rdlane_f(rs, 8 * blk + t);   // rows >= n: lrow == 0 and x_j == 0
 }
 
+// L^T x = y from the packed factor in LDS (lane c -> x_c, replicated in both halves); y in r, 1/L_cc in myinv
+MJB_DEV float mfma_backward32(const float* W, int n, int c_, float myinv, float r) {
+  float rs = r * myinv;
+  const float* Wc = W + c_;
+  float cur[8], nxt[8];
+  const int top = (n - 1) >> 3;
+  mfma_back_load8(cur, Wc, top, n);
+#pragma unroll
+  for (int blk = 3; blk >= 0; blk--) {
+    if (blk > top) continue;
+    if (blk > 0) mfma_back_load8(nxt, Wc, blk - 1, n);
+    mfma_back_chain8(cur, blk, n, c_, myinv, rs);
+#pragma unroll
+    for (int t = 0; t < 8; t++) cur[t] = nxt[t];
+  }
+  return rs;
+}
+// Solve with the factor that is already in LDS (Newton iterations whose active set did not change): forward substitution
+// in the same style - lane c keeps r_c / L_cc, so column j costs one v_readlane + one FMA; L[c][j] comes from the lane's own
+// row (row base + immediate j), 8 columns per batch of loads - then the backward substitution above.
+MJB_DEV void mfma_solve32(const float* W, const float* dinv, float* x, int n, int lane) {
+  const int h = lane >> 5, c_ = lane & 31;
+  const float myinv = c_ < n ? dinv[c_] : 1.0f;
+  float rs = (c_ < n ? x[c_] : 0.0f) * myinv;
+  const float* Wr = W + tri_at(c_ < n ? c_ : 0, 0);
+  const int top = (n - 1) >> 3;
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {
+    if (blk > top) continue;
+    float lrow[8];
+    int c = c_;
+    asm volatile("" : "+v"(c));
+#pragma unroll
+    for (int t = 0; t < 8; t++) lrow[t] = Wr[8 * blk + t];      // L[c][j]; j >= c reads past the row: masked below
+#pragma unroll
+    for (int t = 0; t < 8; t++) { const int j = 8 * blk + t; lrow[t] = (j < c && c < n) ? lrow[t] * myinv : 0.0f; }
+#pragma unroll
+    for (int t = 0; t < 8; t++) rs -= lrow[t] * rdlane_f(rs, 8 * blk + t);
+  }
+  // rs_c = y_c (forward-substituted, already divided by L_cc): the backward pass wants y_c and multiplies by 1/L_cc itself
+  float r = mfma_backward32(W, n, c_, myinv, rs);
+  if (h == 0 && c_ < n) x[c_] = r;
+  gsync<64>();
+}
 template <typename MRef>
 MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
   const int h = lane >> 5, c_ = lane & 31;
@@ -690,19 +734,7 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
   if (h == 0 && c_ < n) dinv[c_] = myinv;
   gsync<64>();
   if (x) {                                                    // backward substitution L^T x = y from the packed factor in LDS
-    float rs = r * myinv;
-    const float* Wc = W + c_;
-    float cur[8], nxt[8];
-    const int top = (n - 1) >> 3;
-    mfma_back_load8(cur, Wc, top, n);
-#pragma unroll
-    for (int blk = 3; blk >= 0; blk--) {
-      if (blk > top) continue;
-      if (blk > 0) mfma_back_load8(nxt, Wc, blk - 1, n);
-      mfma_back_chain8(cur, blk, n, c_, myinv, rs);
-#pragma unroll
-      for (int t = 0; t < 8; t++) cur[t] = nxt[t];
-    }
+    float rs = mfma_backward32(W, n, c_, myinv, r);
     if (h == 0 && c_ < n) x[c_] = rs;
     gsync<64>();
   }
@@ -800,6 +832,7 @@ template <typename MRef>
 MJB_DEV void mfma_sweep_solve32(MRef, const double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 template <typename MRef>
 MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
+MJB_DEV void mfma_solve32(const double*, const double*, double*, int, int) {}
 #endif
 
 // W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
@@ -1938,6 +1971,9 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
   c.pacc[PH_CNT_DIR] += 1; if (rebuild) c.pacc[PH_CNT_FACT] += 1;
 #endif
   if (rebuild) factor_W<T, G>(c, 1, search);
+#ifndef MJB_HOST_EMU
+  else if (fused_inverse_path<T, G>(nv)) { gsync<G>(); mfma_solve32(W, w + L.tmp, search, nv, lane); }
+#endif
   else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
   for (int i = lane; i < nv; i += G) search[i] = -search[i];
   gsync<G>();
