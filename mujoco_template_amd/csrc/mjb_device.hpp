@@ -1496,6 +1496,26 @@ template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
 // ---------------------------------------------------------------------------
 // A6 constraint rows: limits + contacts; impedance, R/D, Jacobian, aref
 // ---------------------------------------------------------------------------
+// impedance and regulariser of one row (the state-dependent half of row_params; K and B are host-folded model constants)
+template <typename T> MJB_DEV void row_imp_R(T pos, T margin, const T* solimp, T diagApprox, T& imp, T& R) {
+  T dmin = t_min(t_max(solimp[0], MJB_MINIMP), MJB_MAXIMP), dmax = t_min(t_max(solimp[1], MJB_MINIMP), MJB_MAXIMP);
+  T width = t_max(solimp[2], (T)0), mid = t_min(t_max(solimp[3], MJB_MINIMP), MJB_MAXIMP), power = t_max(solimp[4], (T)1);
+  if (dmin == dmax || width <= Num<T>::minval()) imp = (T)0.5 * (dmin + dmax);
+  else {
+    T x = t_abs(pos - margin) / width;
+    if (x >= 1) imp = dmax;
+    else if (x <= 0) imp = dmin;
+    else {
+      T y;
+      if (power == 1) y = x;
+      else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+      else if (x <= mid) y = t_pow(x, power) / t_pow(mid, power - 1);
+      else y = 1 - t_pow(1 - x, power) / t_pow(1 - mid, power - 1);
+      imp = dmin + y * (dmax - dmin);
+    }
+  }
+  R = t_max(Num<T>::minval(), (1 - imp) * diagApprox / imp);
+}
 template <typename T> MJB_DEV void row_params(ModelRef<T> m, T pos, T margin, const T* solref, const T* solimp, T diagApprox, T& K, T& B, T& imp, T& R) {
   T dmin = t_min(t_max(solimp[0], MJB_MINIMP), MJB_MAXIMP), dmax = t_min(t_max(solimp[1], MJB_MINIMP), MJB_MAXIMP);
   T width = t_max(solimp[2], (T)0), mid = t_min(t_max(solimp[3], MJB_MINIMP), MJB_MAXIMP), power = t_max(solimp[4], (T)1);
@@ -1543,32 +1563,28 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
       int cnt = 0;
       T dist[2] = {0, 0}, margin = 0;
       bool act[2] = {false, false};
-      if (k < nobj) {
-        bool lim = isj ? (m.jnt_limited[o] && (m.jnt_type[o] == JNT_HINGE || m.jnt_type[o] == JNT_SLIDE)) : (m.tendon_limited[o] != 0);
-        if (lim) {
-          T value = isj ? qpos[m.jnt_qposadr[o]] : tl[o];
-          auto rng = isj ? m.jnt_range + 2 * o : m.tendon_range + 2 * o;
-          margin = isj ? m.jnt_margin[o] : m.tendon_margin[o];
-          dist[0] = value - rng[0]; dist[1] = rng[1] - value;
-          act[0] = dist[0] < margin; act[1] = dist[1] < margin;
-          cnt = (int)act[0] + (int)act[1];
-        }
+      T rec[12];
+      if (k < nobj && m.lim_i[2 * k]) {                         // one record per limit object: no index hops
+        const int vi = m.lim_i[2 * k + 1];
+#pragma unroll
+        for (int q = 0; q < 11; q++) rec[q] = m.lim_f[12 * k + q];
+        T value = isj ? qpos[vi] : tl[vi];
+        margin = rec[2];
+        dist[0] = value - rec[0]; dist[1] = rec[1] - value;
+        act[0] = dist[0] < margin; act[1] = dist[1] < margin;
+        cnt = (int)act[0] + (int)act[1];
       }
       int total, off = gscan_small<G>(cnt, lane, total);
       int row = nefc + off;
       if (cnt > 0) {
-        auto solref = isj ? m.jnt_solref + 2 * o : m.tendon_solref + 2 * o;
-        auto solimp = isj ? m.jnt_solimp + 5 * o : m.tendon_solimp + 5 * o;
-        T sr[2] = {solref[0], solref[1]}, si[5] = {solimp[0], solimp[1], solimp[2], solimp[3], solimp[4]};
-        T diag = isj ? m.dof_invweight0[m.jnt_dofadr[o]] : m.tendon_invweight0[o];
 #pragma unroll
         for (int sd = 0; sd < 2; sd++) {
           if (act[sd]) {
             if (row < cap) {
-              T K, B, imp, R;
-              row_params(m, dist[sd], margin, sr, si, diag, K, B, imp, R);
+              T imp, R;
+              row_imp_R(dist[sd], margin, rec + 6, rec[3], imp, R);
               etype[row] = (isj ? EFC_LIMIT_JOINT : EFC_LIMIT_TENDON) | ((o * 2 + sd) << 9);
-              epos[row] = dist[sd]; emargin[row] = margin; eD[row] = 1 / R; eK[row] = K; eB[row] = B; eI[row] = imp;
+              epos[row] = dist[sd]; emargin[row] = margin; eD[row] = 1 / R; eK[row] = rec[4]; eB[row] = rec[5]; eI[row] = imp;
             }
             row++;
           }
@@ -1587,7 +1603,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     if (ci < c.ncon) {
       p = con_pair[ci] & 0xffff;
       dist = con[ci * CON_STRIDE]; mu = con[ci * CON_STRIDE + 10];
-      incm = m.pair_margin[p] - m.pair_gap[p];
+      incm = m.pair_kb[4 * p];
       if (dist < incm) rows = m.pair_condim[p] == 1 ? 1 : 4;
     }
     int total, off = gscan_small<G>(rows, lane, total);
@@ -1596,14 +1612,12 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
       bool fits = rows > 0 && row + rows <= cap;
       con_pair[ci] = p | ((fits ? row + 1 : 0) << 16);     // bits 16..: first constraint row + 1 (0 = none)
       if (fits) {
-        int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
-        T tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
-        T sr[2] = {m.pair_solref[2 * p], m.pair_solref[2 * p + 1]};
+        const T tran = m.pair_kb[4 * p + 1], K = m.pair_kb[4 * p + 2], B = m.pair_kb[4 * p + 3];
         T si[5] = {m.pair_solimp[5 * p], m.pair_solimp[5 * p + 1], m.pair_solimp[5 * p + 2], m.pair_solimp[5 * p + 3], m.pair_solimp[5 * p + 4]};
-        T K, B, imp, R;
-        if (rows == 1) row_params(m, dist, incm, sr, si, tran, K, B, imp, R);
+        T imp, R;
+        if (rows == 1) row_imp_R(dist, incm, si, tran, imp, R);
         else {
-          row_params(m, dist, incm, sr, si, tran + mu * mu * tran, K, B, imp, R);
+          row_imp_R(dist, incm, si, tran + mu * mu * tran, imp, R);
           R = t_max(Num<T>::minval(), 2 * mu * mu * R);
         }
         for (int r = 0; r < rows; r++) {

@@ -254,6 +254,61 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   m.pair_geom1 = Iq("pair_geom1"); m.pair_geom2 = Iq("pair_geom2"); m.pair_condim = Iq("pair_condim");
   m.pair_friction = F("pair_friction"); m.pair_solref = F("pair_solref"); m.pair_solimp = F("pair_solimp"); m.pair_margin = F("pair_margin"); m.pair_gap = F("pair_gap");
   {
+    // constraint-row constants folded on the host: K, B of a row depend only on solref, solimp[1] and the timestep
+    const double MINIMP = 0.0001, MAXIMP = 0.9999, MINVAL = 1e-15;
+    auto KB = [&](const double* solref, double dmax_raw, double& K, double& B) {
+      const double dmax = std::min(std::max(dmax_raw, MINIMP), MAXIMP);
+      if (solref[0] > 0) {
+        const double tc = std::max(solref[0], 2 * h.timestep), dr = solref[1];
+        K = 1 / std::max(MINVAL, dmax * dmax * tc * tc * dr * dr);
+        B = 2 / std::max(MINVAL, dmax * tc);
+      } else {
+        K = -solref[0] / std::max(MINVAL, dmax * dmax);
+        B = -solref[1] / std::max(MINVAL, dmax);
+      }
+    };
+    const auto& g1 = h.I("pair_geom1"); const auto& g2 = h.I("pair_geom2"); const auto& gb = h.I("geom_bodyid");
+    const auto& pm = h.D("pair_margin"); const auto& pg = h.D("pair_gap"); const auto& psr = h.D("pair_solref"); const auto& psi = h.D("pair_solimp");
+    const auto& biw = h.D("body_invweight0");
+    std::vector<T> kb((size_t)h.npair * 4);
+    for (int p = 0; p < h.npair; p++) {
+      double K, B;
+      KB(&psr[2 * p], psi[5 * p + 1], K, B);
+      kb[4 * p] = (T)(pm[p] - pg[p]);
+      kb[4 * p + 1] = (T)(biw[2 * gb[g1[p]]] + biw[2 * gb[g2[p]]]);
+      kb[4 * p + 2] = (T)K; kb[4 * p + 3] = (T)B;
+    }
+    m.pair_kb = (FP)alloc.putf(kb);
+    const int nobj = h.njnt + h.ntendon;
+    std::vector<T> lf((size_t)nobj * 12, (T)0);
+    std::vector<int> li((size_t)nobj * 2, 0);
+    const auto& jl = h.I("jnt_limited"); const auto& jt = h.I("jnt_type"); const auto& jq = h.I("jnt_qposadr"); const auto& jd = h.I("jnt_dofadr");
+    const auto& jr = h.D("jnt_range"); const auto& jm = h.D("jnt_margin"); const auto& jsr = h.D("jnt_solref"); const auto& jsi = h.D("jnt_solimp");
+    const auto& diw = h.D("dof_invweight0");
+    for (int o = 0; o < h.njnt; o++) {
+      double K, B;
+      KB(&jsr[2 * o], jsi[5 * o + 1], K, B);
+      T* r = &lf[(size_t)o * 12];
+      r[0] = (T)jr[2 * o]; r[1] = (T)jr[2 * o + 1]; r[2] = (T)jm[o]; r[3] = (T)diw[jd[o]]; r[4] = (T)K; r[5] = (T)B;
+      for (int k = 0; k < 5; k++) r[6 + k] = (T)jsi[5 * o + k];
+      li[2 * o] = (jl[o] && (jt[o] == JNT_HINGE || jt[o] == JNT_SLIDE)) ? 1 : 0; li[2 * o + 1] = jq[o];
+    }
+    if (h.ntendon > 0) {
+      const auto& tl = h.I("tendon_limited"); const auto& tr = h.D("tendon_range"); const auto& tm = h.D("tendon_margin");
+      const auto& tsr = h.D("tendon_solref"); const auto& tsi = h.D("tendon_solimp"); const auto& tiw = h.D("tendon_invweight0");
+      for (int t = 0; t < h.ntendon; t++) {
+        double K, B;
+        KB(&tsr[2 * t], tsi[5 * t + 1], K, B);
+        T* r = &lf[(size_t)(h.njnt + t) * 12];
+        r[0] = (T)tr[2 * t]; r[1] = (T)tr[2 * t + 1]; r[2] = (T)tm[t]; r[3] = (T)tiw[t]; r[4] = (T)K; r[5] = (T)B;
+        for (int k = 0; k < 5; k++) r[6 + k] = (T)tsi[5 * t + k];
+        li[2 * (h.njnt + t)] = tl[t] != 0 ? 1 : 0; li[2 * (h.njnt + t) + 1] = t;
+      }
+    }
+    m.lim_f = (FP)alloc.putf(lf);
+    m.lim_i = (IP)alloc.puti(li);
+  }
+  {
     // bounding radius of every geom about its centre (conservative), folded with the pair margin for the broad phase
     const auto& gt = h.I("geom_type"); const auto& gs = h.D("geom_size");
     const auto& g1 = h.I("pair_geom1"); const auto& g2 = h.I("pair_geom2"); const auto& pm = h.D("pair_margin");

@@ -65,6 +65,9 @@ struct DevModel {
   // collision pairs
   IP pair_geom1, pair_geom2, pair_condim;
   FP pair_friction, pair_solref, pair_solimp, pair_margin, pair_gap;
+  FP pair_kb;        // per pair: margin - gap, body_invweight0 sum (translational), K, B of the contact rows (all model constants)
+  FP lim_f;          // per limit object (joints, then tendons) x 12: range lo/hi, margin, diagApprox, K, B, solimp[5], pad
+  IP lim_i;          // per limit object x 2: limited-and-limitable flag, index of the value (qpos address / tendon id)
   FP pair_cull;      // broad phase: r1 + r2 + margin (bounding radii); NEGATED when geom1 is a plane (then r2 + margin)
   // keyframes
   FP key_qpos, key_qvel, key_ctrl, key_time;
