@@ -1039,10 +1039,10 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
   }
   // (1) local poses; xpos/xquat/xanchor/xaxis temporarily hold parent-frame values
   for (int b = 1 + lane; b < m.nbody; b += G) {
-    int jadr = m.body_jntadr[b], jnum = m.body_jntnum[b];
+    const int jadr = m.body_irec[4 * b], jnum = m.body_irec[4 * b + 1], jt0 = m.body_irec[4 * b + 2];
     T pos[3], quat[4], R[9];
-    if (jnum == 1 && m.jnt_type[jadr] == JNT_FREE) {
-      int qa = m.jnt_qposadr[jadr];
+    if (jnum == 1 && jt0 == JNT_FREE) {
+      int qa = m.jnt_irec[2 * jadr + 1];
       quat[0] = qpos[qa + 3]; quat[1] = qpos[qa + 4]; quat[2] = qpos[qa + 5]; quat[3] = qpos[qa + 6];
       quat_normalize(quat);
       qpos[qa + 3] = quat[0]; qpos[qa + 4] = quat[1]; qpos[qa + 5] = quat[2]; qpos[qa + 6] = quat[3];
@@ -1055,10 +1055,10 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
 #pragma unroll
       for (int k = 0; k < 4; k++) quat[k] = m.body_quat[4 * b + k];
       for (int j = jadr; j < jadr + jnum; j++) {
-        T jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
-        T ja[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
-        int qa = m.jnt_qposadr[j];
-        T val = qpos[qa] - m.qpos0[qa];
+        T jp[3] = {m.jnt_rec[8 * j], m.jnt_rec[8 * j + 1], m.jnt_rec[8 * j + 2]};
+        T ja[3] = {m.jnt_rec[8 * j + 3], m.jnt_rec[8 * j + 4], m.jnt_rec[8 * j + 5]};
+        const int jtype = m.jnt_irec[2 * j], qa = m.jnt_irec[2 * j + 1];
+        T val = qpos[qa] - m.jnt_rec[8 * j + 6];
         T anchor[3], axis[3];
         quat2mat(R, quat);
         mulmatvec3(anchor, R, jp);
@@ -1066,7 +1066,7 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
         mulmatvec3(axis, R, ja);
         xanchor[3 * j] = anchor[0]; xanchor[3 * j + 1] = anchor[1]; xanchor[3 * j + 2] = anchor[2];
         xaxis[3 * j] = axis[0]; xaxis[3 * j + 1] = axis[1]; xaxis[3 * j + 2] = axis[2];
-        if (m.jnt_type[j] == JNT_SLIDE) {
+        if (jtype == JNT_SLIDE) {
           pos[0] += axis[0] * val; pos[1] += axis[1] * val; pos[2] += axis[2] * val;
         } else {
           T ql[4], qn[4], v[3];
@@ -1664,7 +1664,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
       int row = (con_pair[ci] >> 16) - 1;
       if (row < 0) continue;
       int p = con_pair[ci] & 0xffff;
-      int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
+      int b1 = m.pair_body[2 * p], b2 = m.pair_body[2 * p + 1];
       const T* cc = con + ci * CON_STRIDE;
       T pos[3] = {cc[1], cc[2], cc[3]}, j1[3], j2[3], dj[3];
       jac_col<T>(c, b1, i, pos, j1, (T*)0);

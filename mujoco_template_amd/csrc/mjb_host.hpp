@@ -279,6 +279,9 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
       kb[4 * p + 2] = (T)K; kb[4 * p + 3] = (T)B;
     }
     m.pair_kb = (FP)alloc.putf(kb);
+    std::vector<int> pb((size_t)h.npair * 2);
+    for (int p = 0; p < h.npair; p++) { pb[2 * p] = gb[g1[p]]; pb[2 * p + 1] = gb[g2[p]]; }
+    m.pair_body = (IP)alloc.puti(pb);
     const int nobj = h.njnt + h.ntendon;
     std::vector<T> lf((size_t)nobj * 12, (T)0);
     std::vector<int> li((size_t)nobj * 2, 0);
@@ -307,6 +310,19 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
     }
     m.lim_f = (FP)alloc.putf(lf);
     m.lim_i = (IP)alloc.puti(li);
+    // kinematics records
+    const auto& jp = h.D("jnt_pos"); const auto& ja = h.D("jnt_axis"); const auto& q0 = h.D("qpos0");
+    std::vector<T> jrec((size_t)h.njnt * 8, (T)0);
+    std::vector<int> jirec((size_t)h.njnt * 2, 0);
+    for (int j = 0; j < h.njnt; j++) {
+      for (int k = 0; k < 3; k++) { jrec[8 * j + k] = (T)jp[3 * j + k]; jrec[8 * j + 3 + k] = (T)ja[3 * j + k]; }
+      jrec[8 * j + 6] = (T)q0[jq[j]];
+      jirec[2 * j] = jt[j]; jirec[2 * j + 1] = jq[j];
+    }
+    const auto& bja = h.I("body_jntadr"); const auto& bjn = h.I("body_jntnum");
+    std::vector<int> birec((size_t)h.nbody * 4, 0);
+    for (int b = 0; b < h.nbody; b++) { birec[4 * b] = bja[b]; birec[4 * b + 1] = bjn[b]; birec[4 * b + 2] = bjn[b] > 0 ? jt[bja[b]] : -1; }
+    m.jnt_rec = (FP)alloc.putf(jrec); m.jnt_irec = (IP)alloc.puti(jirec); m.body_irec = (IP)alloc.puti(birec);
   }
   {
     // bounding radius of every geom about its centre (conservative), folded with the pair margin for the broad phase

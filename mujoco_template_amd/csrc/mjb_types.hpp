@@ -67,6 +67,10 @@ struct DevModel {
   FP pair_friction, pair_solref, pair_solimp, pair_margin, pair_gap;
   FP pair_kb;        // per pair: margin - gap, body_invweight0 sum (translational), K, B of the contact rows (all model constants)
   FP lim_f;          // per limit object (joints, then tendons) x 12: range lo/hi, margin, diagApprox, K, B, solimp[5], pad
+  FP jnt_rec;        // per joint x 8: jnt_pos[3], jnt_axis[3], qpos0[jnt_qposadr], pad   (kinematics: one record, no second hop)
+  IP jnt_irec;       // per joint x 2: type, qposadr
+  IP body_irec;      // per body x 4: jntadr, jntnum, type of the first joint (-1 if none), pad
+  IP pair_body;      // per pair x 2: bodies of geom1 / geom2 (folds geom_bodyid[pair_geom*])
   IP lim_i;          // per limit object x 2: limited-and-limitable flag, index of the value (qpos address / tendon id)
   FP pair_cull;      // broad phase: r1 + r2 + margin (bounding radii); NEGATED when geom1 is a plane (then r2 + margin)
   // keyframes
