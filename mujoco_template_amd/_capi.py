@@ -15,7 +15,7 @@ from typing import Sequence
 import numpy as np
 
 from ._pack import PackedTable
-from .exceptions import ConfigError, NameLookupError, TemplateError
+from .exceptions import ConfigError, NameLookupError, TemplateError, raise_for_status
 from .mjcf import CompiledModel
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -99,17 +99,9 @@ def load_library() -> ctypes.CDLL:
 
 
 def _check(rc: int) -> None:
-    """Map C status codes onto the reference's exception hierarchy (exceptions.py:4-21)."""
-    if rc == 0:
-        return
-    msg = load_library().mjb_last_error().decode()
-    if rc == -1:
-        raise ConfigError(msg)
-    if rc == -2:
-        raise ValueError(msg)
-    if rc == -4:
-        raise NameLookupError(msg)
-    raise TemplateError(msg)
+    """Turn a C status code into the exception of ``exceptions.raise_for_status``."""
+    if rc != 0:
+        raise_for_status(rc, load_library().mjb_last_error().decode())
 
 
 class _CudaArray:

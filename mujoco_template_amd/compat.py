@@ -1,5 +1,13 @@
-"""Setup-time controller/model diagnostics (reference ``mujoco_template/compat.py:31-127``).
-Not on the per-step path; kept so ``Env`` surfaces the same warnings/failures."""
+"""Does this controller fit this model?  Setup-time diagnostics, never on the per-step path.
+
+``check_controller_compat(model, capabilities, enabled_mask)`` returns the reference's ``CompatibilityReport``
+(``mujoco_template/compat.py:11-127``): hard *reasons* make ``assert_ok()`` raise ``CompatibilityError``; everything else
+is a *warning* that ``Env`` relays once through ``info["compat_warnings"]``.
+
+The checks are table-driven: every control space names the per-actuator (flag, range) pair that has to be sane for
+it - servo-like spaces need a bounded ``ctrlrange``, ``intvelocity`` additionally a bounded ``actrange``, torque control only
+looks at force limits that are switched on - and one routine walks the enabled actuators of the batch's (shared) model.
+"""
 
 from __future__ import annotations
 
@@ -11,6 +19,9 @@ import numpy as np
 from .control import ControlSpace, ControllerCapabilities
 from .exceptions import CompatibilityError, ConfigError
 
+_SERVO_SPACES = (ControlSpace.POSITION, ControlSpace.VELOCITY, ControlSpace.INTVELOCITY)
+_CLOSING_NOTE = "Note: joint/tendon constraints or other clamps may still limit motion/force beyond actuator-level checks."
+
 
 @dataclass
 class CompatibilityReport:
@@ -19,62 +30,72 @@ class CompatibilityReport:
     warnings: list[str] = field(default_factory=list)
 
     def assert_ok(self) -> None:
-        if not self.ok:
-            raise CompatibilityError("\n".join(["Incompatible controller/model:"] + [f"- {r}" for r in self.reasons]))
+        if self.ok:
+            return
+        bullet_list = "".join(f"\n- {why}" for why in self.reasons)
+        raise CompatibilityError("Incompatible controller/model:" + bullet_list)
 
 
-def _bad_range(lo: float, hi: float) -> bool:
-    return not (np.isfinite(lo) and np.isfinite(hi) and hi > lo)
+def _range_is_usable(pair: np.ndarray) -> bool:
+    lo, hi = float(pair[0]), float(pair[1])
+    return bool(np.isfinite(lo) and np.isfinite(hi) and hi > lo)
+
+
+def _range_findings(model: Any, actuators: np.ndarray, flag_field: str, range_field: str, label: str,
+                    unflagged: str | None) -> list[str]:
+    """Walk the enabled actuators: ``unflagged`` (if given) is reported where the limit flag is off, an unusable range where it is on."""
+    flags = np.asarray(getattr(model, flag_field), dtype=bool)
+    ranges = np.asarray(getattr(model, range_field), dtype=float).reshape(-1, 2)
+    found: list[str] = []
+    for a in actuators:
+        if not flags[a]:
+            if unflagged is not None:
+                found.append(unflagged.format(a=int(a)))
+        elif not _range_is_usable(ranges[a]):
+            found.append(f"Invalid {label} for enabled actuator {int(a)}: [{ranges[a][0]}, {ranges[a][1]}]")
+    return found
+
+
+def _group_findings(model: Any, capabilities: ControllerCapabilities, actuators: np.ndarray) -> list[str]:
+    if capabilities.actuator_groups is None:
+        return []
+    asked = {int(g) for g in capabilities.actuator_groups}
+    live = {int(g) for g in np.asarray(model.actuator_group)[actuators]}
+    found: list[str] = []
+    if not live:
+        found.append("Controller declared actuator groups but none are currently enabled; continuing without additional group gating.")
+    if asked - live:
+        found.append(f"Controller requested actuator groups {sorted(asked - live)} but they are not enabled; "
+                     "controller will still run with the available groups.")
+    if live - asked:
+        found.append(f"Enabled actuators include groups {sorted(live - asked)} beyond the controller request; "
+                     "behaviour matches MuJoCo but may require controller-side masking.")
+    return found
 
 
 def check_controller_compat(model: Any, ctrl_cap: ControllerCapabilities, enabled_mask: np.ndarray | None) -> CompatibilityReport:
-    reasons: list[str] = []
-    notes: list[str] = []
     nu = int(model.nu)
-    if nu == 0:
-        reasons.append("Model has no actuators (nu=0).")
     mask = np.ones(nu, dtype=bool) if enabled_mask is None else np.asarray(enabled_mask, dtype=bool)
     if mask.shape[0] != nu:
         raise ConfigError("enabled_mask must have length model.nu")
+    reasons: list[str] = []
+    if nu == 0:
+        reasons.append("Model has no actuators (nu=0).")
     if not mask.any():
         reasons.append("All actuators are disabled by group selection.")
-    enabled = np.flatnonzero(mask)
+    live = np.flatnonzero(mask)
 
-    if ctrl_cap.actuator_groups is not None:
-        wanted = {int(g) for g in ctrl_cap.actuator_groups}
-        have = {int(g) for g in np.asarray(model.actuator_group)[enabled]}
-        if not have:
-            notes.append("Controller declared actuator groups but none are currently enabled; continuing without additional group gating.")
-        if sorted(wanted - have):
-            notes.append(f"Controller requested actuator groups {sorted(wanted - have)} but they are not enabled; controller will still run with the available groups.")
-        if sorted(have - wanted):
-            notes.append(f"Enabled actuators include groups {sorted(have - wanted)} beyond the controller request; behaviour matches MuJoCo but may require controller-side masking.")
-
+    notes = _group_findings(model, ctrl_cap, live)
     space = ctrl_cap.control_space
-    if space in (ControlSpace.POSITION, ControlSpace.VELOCITY, ControlSpace.INTVELOCITY):
-        limited = np.asarray(model.actuator_ctrllimited, dtype=bool)
-        rng = np.asarray(model.actuator_ctrlrange).reshape(-1, 2)
-        for a in enabled:
-            if not limited[a]:
-                notes.append(f"Enabled actuator {a} lacks ctrlrange limits required for servo control.")
-            elif _bad_range(*rng[a]):
-                notes.append(f"Invalid ctrlrange for enabled actuator {a}: [{rng[a][0]}, {rng[a][1]}]")
+    if space in _SERVO_SPACES:
+        notes += _range_findings(model, live, "actuator_ctrllimited", "actuator_ctrlrange", "ctrlrange",
+                                 "Enabled actuator {a} lacks ctrlrange limits required for servo control.")
     if space == ControlSpace.INTVELOCITY:
-        actlim = np.asarray(model.actuator_actlimited, dtype=bool)
-        arng = np.asarray(model.actuator_actrange).reshape(-1, 2)
-        for a in enabled:
-            if not actlim[a]:
-                notes.append(f"Enabled actuator {a} has no activation limits (actlimited=0) under intvelocity control.")
-            elif _bad_range(*arng[a]):
-                notes.append(f"Invalid actrange for enabled actuator {a}: [{arng[a][0]}, {arng[a][1]}]")
+        notes += _range_findings(model, live, "actuator_actlimited", "actuator_actrange", "actrange",
+                                 "Enabled actuator {a} has no activation limits (actlimited=0) under intvelocity control.")
     if space == ControlSpace.TORQUE:
-        flim = np.asarray(model.actuator_forcelimited, dtype=bool)
-        frng = np.asarray(model.actuator_forcerange).reshape(-1, 2)
-        for a in enabled:
-            if flim[a] and _bad_range(*frng[a]):
-                notes.append(f"Invalid forcerange for enabled actuator {a}: [{frng[a][0]}, {frng[a][1]}]")
-
-    notes.append("Note: joint/tendon constraints or other clamps may still limit motion/force beyond actuator-level checks.")
+        notes += _range_findings(model, live, "actuator_forcelimited", "actuator_forcerange", "forcerange", None)
+    notes.append(_CLOSING_NOTE)
     return CompatibilityReport(ok=not reasons, reasons=reasons, warnings=notes)
 
 

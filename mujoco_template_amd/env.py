@@ -1,14 +1,18 @@
-"""``Env`` — the step loop over the batched engine.
+"""``Env`` - controller, engine and observation extractor behind one ``step()``.
 
-Signature-compatible with reference ``mujoco_template/env.py:28-260`` (``Env.__init__``,
-``from_xml_path``, ``reset``, ``step``, ``linearize``, ``passive``, ``StepResult``); the
-ordering contract is the reference's: the controller sees the pre-step state and
-``t = data.time``; (A, B) and Jacobians are evaluated after ``ctrl`` is written and before the
-step; ``compat_warnings`` appear in ``info`` once; info-key collisions raise ``TemplateError``.
+API of the reference (``mujoco_template/env.py:20-260``: ``StepResult``, ``Env.__init__``, ``from_xml_path``, ``reset``,
+``step``, ``linearize``, ``passive``) with its ordering guarantees: the controller is called on the PRE-step state with
+``t = data.time``; the discrete linearisation and the requested Jacobians are evaluated after ``ctrl`` was written and
+before the physics advances; compatibility warnings travel in ``info`` exactly once; a user ``info_fn`` may not overwrite
+a key the environment produced (``TemplateError``).
 
-New, keyword-only: ``batch`` / ``dtype`` / ``device`` / ``lanes`` / ``nconmax`` / ``nefcmax`` /
-``env0`` on ``from_xml_path``, and :meth:`Env.rollout` — K fused steps in one kernel launch when
-the controller runs on the device (``ZeroController``, ``RandomCtrlController``).
+What the batched engine adds:
+
+* ``from_xml_path(..., batch, dtype, device, lanes, nconmax, nefcmax, env0, specialize)``;
+* two ways through a step.  *Host-driven*: any Python controller, one engine call per sub-step (``_advance_on_host``).
+  *Fused*: a controller whose law the step kernel can evaluate itself (``control.device_ctrl_mode_of``) runs inside ONE
+  kernel launch for all sub-steps (``rollout``); ``step`` picks it automatically;
+* :meth:`Env.rollout` - the fused path exposed directly, optionally filling a device-side observation ring.
 """
 
 from __future__ import annotations
@@ -23,12 +27,14 @@ import numpy as np
 from ._capi import CTRL_FEEDBACK, CTRL_KEEP, CTRL_RANDOM, CTRL_ZERO
 from ._typing import InfoDict, JacobiansDict, Observation
 from .compat import check_controller_compat
-from .control import Controller
+from .control import Controller, device_ctrl_mode_of
 from .exceptions import ConfigError, TemplateError
 from .jacobians import compute_requested_jacobians
 from .linearization import linearize_discrete
 from .model import ModelHandle
 from .observations import ObservationExtractor, ObservationSpec
+
+_KERNEL_MODE = {"zero": CTRL_ZERO, "random": CTRL_RANDOM, "feedback": CTRL_FEEDBACK}
 
 
 @dataclass
@@ -39,6 +45,11 @@ class StepResult:
     info: InfoDict
 
 
+def _one_or_all(history: list) -> Any:
+    """A single sub-step reports its value bare, several sub-steps report the list (reference env.py:203-215)."""
+    return history[0] if len(history) == 1 else history
+
+
 class Env:
     def __init__(self, handle: ModelHandle, obs_spec: ObservationSpec | None = None, controller: Controller | None = None,
                  reward_fn: Callable[[Any, Any, Observation | None], float] | None = None,
@@ -47,39 +58,38 @@ class Env:
                  enabled_groups: Iterable[int] | None = None, control_decimation: int = 1):
         if control_decimation < 1:
             raise ConfigError("control_decimation must be >= 1")
-        self.handle = handle
-        self.model = handle.model
-        self.data = handle.data
-        self._obs_spec = obs_spec
-        self.extractor: ObservationExtractor | None = None if obs_spec is None else ObservationExtractor(handle.model, obs_spec)
+        self.handle, self.model, self.data = handle, handle.model, handle.data
         self.controller = controller
         self.reward_fn, self.done_fn, self.info_fn = reward_fn, done_fn, info_fn
         self.control_decimation = int(control_decimation)
-        self._substep = 0
-        self._added_warnings = False
+        self._obs_spec = obs_spec
+        self.extractor: ObservationExtractor | None = ObservationExtractor(handle.model, obs_spec) if obs_spec is not None else None
+        self._substep = 0                 # physics steps since reset (decimation phase)
+        self._device_steps = 0            # same count, as the step index of the device-side RNG stream
+        self._warnings_reported = False
         self._compat_warnings: list[str] = []
-        self._device_steps = 0
-
-        caps = controller.capabilities if controller is not None else None
-        requested = tuple(int(g) for g in caps.actuator_groups) if caps is not None and caps.actuator_groups is not None else None
-        if enabled_groups is not None:
-            chosen = tuple(int(g) for g in enabled_groups)
-            if requested is not None and set(requested) != set(chosen):
-                msg = (f"Controller declares actuator groups {sorted(set(requested))} but user requested "
-                       f"{sorted(set(chosen))}; proceeding with the user selection.")
-                warnings.warn(msg, RuntimeWarning)
-                self._compat_warnings.append(msg)
-            self.handle.set_enabled_actuator_groups(chosen)
-        elif requested is not None:
-            msg = (f"Controller declares actuator groups {sorted(set(requested))} but Env leaves actuator "
-                   "availability unchanged by default.")
-            warnings.warn(msg, RuntimeWarning)
-            self._compat_warnings.append(msg)
+        self._select_actuator_groups(enabled_groups)
         if controller is not None:
             controller.prepare(self.model, self.data)
             report = check_controller_compat(self.model, controller.capabilities, self.handle.enabled_actuator_mask())
-            self._compat_warnings = list(report.warnings)
+            self._compat_warnings = list(report.warnings)     # the report's list replaces the group notes (reference env.py:92)
             report.assert_ok()
+
+    def _select_actuator_groups(self, enabled_groups: Iterable[int] | None) -> None:
+        """The user's ``enabled_groups`` win over the controller's declaration; a mismatch or an ignored declaration warns."""
+        caps = getattr(self.controller, "capabilities", None)
+        declared = None if caps is None or caps.actuator_groups is None else sorted({int(g) for g in caps.actuator_groups})
+        note = None
+        if enabled_groups is not None:
+            chosen = sorted({int(g) for g in enabled_groups})
+            if declared is not None and declared != chosen:
+                note = f"Controller declares actuator groups {declared} but user requested {chosen}; proceeding with the user selection."
+            self.handle.set_enabled_actuator_groups(chosen)
+        elif declared is not None:
+            note = f"Controller declares actuator groups {declared} but Env leaves actuator availability unchanged by default."
+        if note is not None:
+            warnings.warn(note, RuntimeWarning)
+            self._compat_warnings.append(note)
 
     @property
     def compat_warnings(self) -> list[str]:
@@ -91,24 +101,22 @@ class Env:
                       control_decimation: int = 1, auto_reset: bool = True, keyframe: int | str | None = None,
                       batch: int = 1, dtype: str = "float32", device: int = 0, lanes: int = 0, nconmax: int = 0,
                       nefcmax: int = 0, env0: int = 0, specialize: bool | None = None) -> "Env":
-        if obs_spec is None:
-            obs_spec = ObservationSpec(include_sensordata=False)
+        if keyframe is not None and not auto_reset:
+            raise ConfigError("auto_reset=False is incompatible with specifying a keyframe")
         handle = ModelHandle.from_xml_path(xml_path, batch=batch, dtype=dtype, device=device, lanes=lanes, nconmax=nconmax,
                                            nefcmax=nefcmax, env0=env0, specialize=specialize)
         if controller is not None and hasattr(controller, "env0"):
-            controller.env0 = env0
-        env = cls(handle, obs_spec=obs_spec, controller=controller, reward_fn=reward_fn, done_fn=done_fn, info_fn=info_fn,
+            controller.env0 = env0                  # device-side RNG streams are keyed by the GLOBAL environment index
+        env = cls(handle, obs_spec=obs_spec if obs_spec is not None else ObservationSpec(include_sensordata=False),
+                  controller=controller, reward_fn=reward_fn, done_fn=done_fn, info_fn=info_fn,
                   enabled_groups=enabled_groups, control_decimation=control_decimation)
-        if keyframe is not None and not auto_reset:
-            raise ConfigError("auto_reset=False is incompatible with specifying a keyframe")
         if auto_reset:
             env.reset(keyframe)
         return env
 
     def _ensure_extractor(self) -> ObservationExtractor:
         if self.extractor is None:
-            if self._obs_spec is None:
-                self._obs_spec = ObservationSpec()
+            self._obs_spec = self._obs_spec or ObservationSpec()
             self.extractor = ObservationExtractor(self.model, self._obs_spec)
         return self.extractor
 
@@ -118,27 +126,27 @@ class Env:
         else:
             self.handle.reset_keyframe(keyframe)
         self.handle.forward()
-        self._substep = 0
-        self._added_warnings = False
-        self._device_steps = 0
+        self._substep = self._device_steps = 0
+        self._warnings_reported = False
         if self.controller is not None:
-            self.controller.prepare(self.model, self.data)
+            self.controller.prepare(self.model, self.data)     # several example controllers write qpos/qvel/ctrl here
         return self._ensure_extractor()(self.data)
 
-    # -- fused device path --------------------------------------------------------------------
+    # -- fused path ---------------------------------------------------------------------------------
     def _device_mode(self) -> int | None:
+        """Kernel ctrl mode when the whole step can stay on the GPU; ``None`` when the host has to drive it."""
         if self.controller is None:
             return CTRL_KEEP
-        mode = getattr(self.controller, "device_ctrl_mode", None)
-        caps = self.controller.capabilities
-        if mode is None or caps.needs_linearization or tuple(caps.needs_jacobians) or self.control_decimation != 1:
+        if self.control_decimation != 1:
             return None
-        return {"zero": CTRL_ZERO, "random": CTRL_RANDOM, "feedback": CTRL_FEEDBACK}.get(mode)
+        name = device_ctrl_mode_of(self.controller)
+        return None if name is None else _KERNEL_MODE[name]
 
     def can_fuse(self) -> bool:
-        """True when nothing on the host has to observe individual steps (controller on device, no reward/done/info hooks)."""
-        extras = bool(self.extractor.extra_items) if self.extractor is not None else False
-        return self._device_mode() is not None and not any((self.reward_fn, self.done_fn, self.info_fn)) and not extras
+        """Nothing on the host needs to see individual steps: device controller, no reward / done / info hooks, no extras."""
+        if self._device_mode() is None or self.reward_fn or self.done_fn or self.info_fn:
+            return False
+        return not (self.extractor is not None and self.extractor.extra_items)
 
     def rollout(self, nsteps: int, *, obs_every: int = 0, obs_out=None, obs_spec_handle=None):
         """Advance ``nsteps`` in ONE kernel launch (controller evaluated on the device).
@@ -152,14 +160,11 @@ class Env:
             raise ConfigError("Env.rollout needs a device-side controller (ZeroController / RandomCtrlController) or none")
         if nsteps < 1:
             raise ConfigError("Env.rollout(nsteps): nsteps must be >= 1")
-        data, sim = self.data, self.data.sim
+        data, sim, ctl = self.data, self.data.sim, self.controller
         data.push_host_edits()
-        seed = int(getattr(self.controller, "seed", 0))
-        scale = float(getattr(self.controller, "scale", 1.0))
         if mode == CTRL_FEEDBACK:
-            ctl = self.controller
             sim.set_feedback(ctl.K, ctl.ctrl0, ctl.qpos_goal, ctl.qvel_goal)
-        spec = ptr = None
+        spec, ring_ptr = None, 0
         if obs_every > 0:
             import torch
 
@@ -167,57 +172,56 @@ class Env:
             if obs_out is None:
                 obs_out = torch.empty((nsteps // obs_every, data.batch, spec.dim), device=f"cuda:{sim.device}",
                                       dtype=torch.float32 if sim.dtype == "float32" else torch.float64)
-            ptr = obs_out.data_ptr()
-        sim.rollout(nsteps, mode, seed=seed, step0=self._device_steps, ctrl_scale=scale, obs_spec=spec, obs_out_ptr=ptr or 0, obs_every=obs_every)
+            ring_ptr = obs_out.data_ptr()
+        sim.rollout(nsteps, mode, seed=int(getattr(ctl, "seed", 0)), step0=self._device_steps,
+                    ctrl_scale=float(getattr(ctl, "scale", 1.0)), obs_spec=spec, obs_out_ptr=ring_ptr, obs_every=obs_every)
         self._device_steps += nsteps
         self._substep += nsteps
-        if hasattr(self.controller, "step_count"):
-            self.controller.step_count = self._device_steps
+        if hasattr(ctl, "step_count"):
+            ctl.step_count = self._device_steps
         data.mark_device_newer()
         return obs_out
 
-    # -- reference step loop ----------------------------------------------------------------------
+    # -- host-driven path --------------------------------------------------------------------------
+    def _advance_on_host(self, n: int, info: InfoDict) -> None:
+        """``n`` physics steps with the Python controller in the loop; per-sub-step (A, B) / Jacobians go into ``info``."""
+        ctl = self.controller
+        caps = ctl.capabilities if ctl is not None else None
+        lin_A: list[np.ndarray] = []
+        lin_B: list[np.ndarray] = []
+        jacs: list[JacobiansDict] = []
+        for _ in range(n):
+            if ctl is not None and self._substep % self.control_decimation == 0:
+                ctl(self.model, self.data, _scalar_time(self.data.time))
+                if caps.needs_linearization:
+                    A, B = linearize_discrete(self.model, self.data, use_native=True)
+                    lin_A.append(A); lin_B.append(B)
+                if caps.needs_jacobians:
+                    jacs.append(compute_requested_jacobians(self.model, self.data, caps.needs_jacobians))
+            self.handle.step()
+            self._substep += 1
+            self._device_steps += 1
+        if lin_A:
+            info["A"], info["B"] = _one_or_all(lin_A), _one_or_all(lin_B)
+        if jacs:
+            info["jacobians"] = _one_or_all(jacs)
+
     def step(self, n: int = 1, *, return_obs: bool = True) -> StepResult:
         if n < 1:
             raise ConfigError("Env.step(n): n must be >= 1")
         info: InfoDict = {}
-        if not self._added_warnings and self._compat_warnings:
+        if self._compat_warnings and not self._warnings_reported:
             info["compat_warnings"] = list(self._compat_warnings)
-            self._added_warnings = True
-
-        if self._device_mode() is not None and self.controller is not None:
-            self.rollout(n)                       # controller + n steps fused on the device
+            self._warnings_reported = True
+        if self.controller is not None and self._device_mode() is not None:
+            self.rollout(n)                        # controller + n steps in one launch
             self.data.sync_host()
         else:
-            hist_A: list[np.ndarray] = []
-            hist_B: list[np.ndarray] = []
-            hist_J: list[JacobiansDict] = []
-            for _ in range(n):
-                if self.controller is not None and self._substep % self.control_decimation == 0:
-                    self.controller(self.model, self.data, _scalar_time(self.data.time))
-                    caps = self.controller.capabilities
-                    if caps.needs_linearization:
-                        A, B = linearize_discrete(self.model, self.data, use_native=True)
-                        hist_A.append(A)
-                        hist_B.append(B)
-                    if caps.needs_jacobians:
-                        hist_J.append(compute_requested_jacobians(self.model, self.data, caps.needs_jacobians))
-                self.handle.step()
-                self._substep += 1
-                self._device_steps += 1
-            if hist_A:
-                info["A"] = hist_A[0] if len(hist_A) == 1 else hist_A
-                info["B"] = hist_B[0] if len(hist_B) == 1 else hist_B
-            if hist_J:
-                info["jacobians"] = hist_J[0] if len(hist_J) == 1 else hist_J
-
+            self._advance_on_host(n, info)
         obs: Observation | None = self._ensure_extractor()(self.data) if return_obs else None
-        reward: float | None = None
-        done = False
-        if self.reward_fn:
-            reward = self.reward_fn(self.model, self.data, obs)
-        if self.done_fn:
-            done = bool(self.done_fn(self.model, self.data, obs))
+        # the user hooks run even without an observation (they then receive obs=None), like the reference
+        reward = self.reward_fn(self.model, self.data, obs) if self.reward_fn else None
+        done = bool(self.done_fn(self.model, self.data, obs)) if self.done_fn else False
         if self.info_fn:
             for key, value in self.info_fn(self.model, self.data, obs).items():
                 if key in info:
@@ -237,6 +241,7 @@ class Env:
 
 
 def _scalar_time(t: Any) -> float:
+    """The controller's ``t``: the clock of environment 0 (all environments share the timestep)."""
     return float(t) if np.ndim(t) == 0 else float(np.asarray(t).flat[0])
 
 

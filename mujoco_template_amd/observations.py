@@ -1,9 +1,17 @@
-"""Declarative observations (reference ``mujoco_template/observations.py:34-174``).
+"""What an environment reports after a step, declared once.
 
-``ObservationExtractor.__call__`` keeps the reference's host semantics (dict of zero-copy
-views, or a flat array concatenated in ``sorted(keys)`` order) over the batched data proxy.
-``gather_device`` is the batched fast path: one HIP gather kernel writes the same flat
-layout ``[batch, obs_dim]`` on the GPU (``mjb_obs_gather``), ready for an RCCL all-gather.
+``ObservationSpec`` / ``ObservationProducer`` / ``ObservationExtractor`` carry the reference's names, fields and defaults
+(``mujoco_template/observations.py:20-174``).  The extractor serves two consumers:
+
+* **host** - ``extractor(data)`` returns the mapping ``field -> array`` (views that alias the data object's host mirrors
+  unless ``copy`` asks otherwise; position blocks are always fresh arrays) or, with ``as_dict=False``, one flat vector
+  laid out in ``sorted(field names)`` order.  With ``batch > 1`` every array has a leading batch axis and the flat form
+  is ``[batch, obs_dim]``;
+* **device** - ``gather_device`` / ``device_spec``: the same flat layout written by a gather kernel (``mjb_obs_gather``)
+  or straight into the observation ring of a fused rollout, ready for the RCCL all-gather.
+
+The state fields are described by one table (flag on the spec, attribute on the data object); name -> id resolution of
+sites / bodies / geoms happens once, at construction, and fails with ``NameLookupError`` like the reference.
 """
 
 from __future__ import annotations
@@ -19,19 +27,24 @@ from . import mj
 from ._typing import Observation, ObservationDict
 from .exceptions import ConfigError, NameLookupError
 
+# (spec flag, observation key = attribute of the data object) for the plain state arrays, in the reference's order
+_STATE_FIELDS = (("include_qpos", "qpos"), ("include_qvel", "qvel"), ("include_act", "act"), ("include_ctrl", "ctrl"))
+# bit of each flag in the device gather kernel (include/mjbatch.h mjb_obs_spec_create)
+_DEVICE_BITS = {"include_qpos": 0, "include_qvel": 1, "include_ctrl": 2, "include_sensordata": 3, "include_time": 4, "bodies_inertial": 6}
+
 
 @dataclass(frozen=True)
 class ObservationProducer:
-    """User-defined observation slice; ``copy=None`` inherits the spec-wide flag."""
+    """A user-computed observation entry; ``copy=None`` defers to the spec-wide ``copy`` flag."""
 
     fn: Callable[[Any, Any], np.ndarray | Sequence[float]]
     copy: bool | None = None
 
     def produce(self, model: Any, data: Any, default_copy: bool) -> np.ndarray:
-        value = self.fn(model, data)
-        want_copy = default_copy if self.copy is None else bool(self.copy)
-        arr = value if isinstance(value, np.ndarray) else np.asarray(value)
-        return np.array(arr, copy=True) if want_copy else arr
+        raw = self.fn(model, data)
+        arr = raw if isinstance(raw, np.ndarray) else np.asarray(raw)
+        detach = default_copy if self.copy is None else bool(self.copy)
+        return arr.copy() if detach else arr
 
 
 @dataclass
@@ -52,93 +65,88 @@ class ObservationSpec:
     copy: bool = False
 
 
-def _maybe_copy(arr: np.ndarray, copy: bool) -> np.ndarray:
-    return np.array(arr, copy=True) if copy else arr
+def _as_producer(key: str, value: Any) -> ObservationProducer:
+    if isinstance(value, ObservationProducer):
+        return value
+    if callable(value):
+        return ObservationProducer(value)
+    raise TypeError(f"extras[{key!r}] must be callable or ObservationProducer")
 
 
 class ObservationExtractor:
     def __init__(self, model: Any, spec: ObservationSpec):
-        self.model = model
-        self.spec = spec
-        self.site_ids = tuple(self._name2id(mj.mjtObj.mjOBJ_SITE, n) for n in spec.sites_pos)
-        self.body_ids = tuple(self._name2id(mj.mjtObj.mjOBJ_BODY, n) for n in spec.bodies_pos)
-        self.geom_ids = tuple(self._name2id(mj.mjtObj.mjOBJ_GEOM, n) for n in spec.geoms_pos)
-        self.subtree_ids = tuple(self._name2id(mj.mjtObj.mjOBJ_BODY, n) for n in spec.subtree_com)
-        self.extra_items = tuple((name, self._normalize_extra(name, p)) for name, p in spec.extras.items())
+        self.model, self.spec = model, spec
+
+        def ids(kind: int, names: Sequence[str]) -> tuple[int, ...]:
+            found = []
+            for name in names:
+                idx = int(mj.mj_name2id(model, kind, name))
+                if idx < 0:
+                    raise NameLookupError(f"Name not found in model: {name}")
+                found.append(idx)
+            return tuple(found)
+
+        self.site_ids = ids(mj.mjtObj.mjOBJ_SITE, spec.sites_pos)
+        self.body_ids = ids(mj.mjtObj.mjOBJ_BODY, spec.bodies_pos)
+        self.geom_ids = ids(mj.mjtObj.mjOBJ_GEOM, spec.geoms_pos)
+        self.subtree_ids = ids(mj.mjtObj.mjOBJ_BODY, spec.subtree_com)
+        self.extra_items = tuple((key, _as_producer(key, value)) for key, value in spec.extras.items())
         self._warned_missing_sensordata = False
         self._dev_spec = None
         self._dev_out = None
 
-    def _name2id(self, objtype: int, name: str) -> int:
-        idx = int(mj.mj_name2id(self.model, objtype, name))
-        if idx < 0:
-            raise NameLookupError(f"Name not found in model: {name}")
-        return idx
+    # -- host ------------------------------------------------------------------------------------
+    def _sensordata(self, data: Any, batched: bool) -> np.ndarray:
+        if self.model.nsensordata > 0:
+            return data.sensordata.copy() if self.spec.copy else data.sensordata
+        if not self._warned_missing_sensordata:
+            warnings.warn("ObservationSpec requested sensordata but model has none; returning an empty array instead.", RuntimeWarning)
+            self._warned_missing_sensordata = True
+        return np.zeros((data.batch, 0)) if batched else np.zeros(0, dtype=float)
 
-    @staticmethod
-    def _normalize_extra(name: str, producer: Any) -> ObservationProducer:
-        if isinstance(producer, ObservationProducer):
-            return producer
-        if callable(producer):
-            return ObservationProducer(producer)
-        raise TypeError(f"extras[{name!r}] must be callable or ObservationProducer")
+    def _position_blocks(self, data: Any) -> ObservationDict:
+        """``[k, 3]`` (``[batch, k, 3]``) selections of the kinematic outputs - always fresh arrays."""
+        spec = self.spec
+        if self.subtree_ids:
+            mj.mj_subtreeCoM(self.model, data)
+        sources = (("sites_pos", self.site_ids, "site_xpos"),
+                   ("bodies_pos", self.body_ids, "xipos" if spec.bodies_inertial else "xpos"),
+                   ("geoms_pos", self.geom_ids, "geom_xpos"),
+                   ("subtree_com", self.subtree_ids, "subtree_com"))
+        return {key: np.array(getattr(data, attr)[..., list(sel), :], dtype=float) for key, sel, attr in sources if sel}
 
-    # -- host path (reference semantics) ------------------------------------------------
     def __call__(self, data: Any) -> Observation:
         spec = self.spec
         batched = getattr(data, "batch", 1) > 1
         out: ObservationDict = {}
-        if spec.include_qpos:
-            out["qpos"] = _maybe_copy(data.qpos, spec.copy)
-        if spec.include_qvel:
-            out["qvel"] = _maybe_copy(data.qvel, spec.copy)
-        if spec.include_act:
-            out["act"] = _maybe_copy(data.act, spec.copy)
-        if spec.include_ctrl:
-            out["ctrl"] = _maybe_copy(data.ctrl, spec.copy)
+        for flag, key in _STATE_FIELDS:
+            if getattr(spec, flag):
+                arr = getattr(data, key)
+                out[key] = arr.copy() if spec.copy else arr
         if spec.include_sensordata:
-            if self.model.nsensordata == 0:
-                if not self._warned_missing_sensordata:
-                    warnings.warn("ObservationSpec requested sensordata but model has none; returning an empty array instead.", RuntimeWarning)
-                    self._warned_missing_sensordata = True
-                out["sensordata"] = np.zeros((data.batch, 0)) if batched else np.zeros(0, dtype=float)
-            else:
-                out["sensordata"] = _maybe_copy(data.sensordata, spec.copy)
+            out["sensordata"] = self._sensordata(data, batched)
         if spec.include_time:
-            out["time"] = np.array(data.time, dtype=float).reshape(-1, 1) if batched else np.array([data.time], dtype=float)
-
-        def rows(src: np.ndarray, ids: tuple[int, ...]) -> np.ndarray:   # always a fresh array, like the reference
-            return np.array(src[..., list(ids), :], dtype=float)
-
-        if self.site_ids:
-            out["sites_pos"] = rows(data.site_xpos, self.site_ids)
-        if self.body_ids:
-            out["bodies_pos"] = rows(data.xipos if spec.bodies_inertial else data.xpos, self.body_ids)
-        if self.geom_ids:
-            out["geoms_pos"] = rows(data.geom_xpos, self.geom_ids)
-        if self.subtree_ids:
-            mj.mj_subtreeCoM(self.model, data)
-            out["subtree_com"] = rows(data.subtree_com, self.subtree_ids)
-        for name, producer in self.extra_items:
-            if name in out:
-                raise ValueError(f"extras[{name!r}] duplicates an existing observation key")
-            out[name] = producer.produce(self.model, data, spec.copy)
+            clock = np.array(data.time, dtype=float)
+            out["time"] = clock.reshape(-1, 1) if batched else clock.reshape(1)
+        out.update(self._position_blocks(data))
+        for key, producer in self.extra_items:
+            if key in out:
+                raise ValueError(f"extras[{key!r}] duplicates an existing observation key")
+            out[key] = producer.produce(self.model, data, spec.copy)
         if spec.as_dict:
             return out
-        keys = sorted(out.keys())
-        if not keys:
+        if not out:
             return np.zeros(0)
+        parts = [np.asarray(out[key]) for key in sorted(out)]
         if batched:
-            return np.concatenate([np.asarray(out[k]).reshape(data.batch, -1) for k in keys], axis=1)
-        return np.concatenate([np.asarray(out[k]).ravel() for k in keys])
+            return np.concatenate([part.reshape(data.batch, -1) for part in parts], axis=1)
+        return np.concatenate([part.ravel() for part in parts])
 
     # -- device path ------------------------------------------------------------------------
     def device_flags(self) -> int:
-        s = self.spec
         if self.extra_items:
             raise ConfigError("user extras are host callables: use the host extractor for specs with extras")
-        return (int(s.include_qpos) | int(s.include_qvel) << 1 | int(s.include_ctrl) << 2 | int(s.include_sensordata) << 3
-                | int(s.include_time) << 4 | int(s.bodies_inertial) << 6)
+        return sum(1 << bit for name, bit in _DEVICE_BITS.items() if getattr(self.spec, name))
 
     def device_spec(self, data: Any):
         if self._dev_spec is None or self._dev_spec.sim is not data.sim:

@@ -1,4 +1,10 @@
-"""In-memory snapshot/restore of the batch state (reference ``mujoco_template/state_utils.py:9-31``)."""
+"""Save and put back the mutable state of a (batched) ``MjData`` - used around every computation that has to
+leave the simulation untouched (``steady_ctrl0``, finite differences on the host).
+
+Same two private helpers as the reference (``mujoco_template/state_utils.py:9-31``); the fields are whatever
+``_FIELDS`` lists, each copied with its batch axis, and ``time`` is restored through the data object's setter so the
+device copy follows.
+"""
 
 from __future__ import annotations
 
@@ -8,23 +14,26 @@ import numpy as np
 
 from ._typing import StateSnapshot
 
+_FIELDS = ("qpos", "qvel", "ctrl")          # writable arrays that exist on every data object
+_OPTIONAL = ("act",)                          # present only for models with actuator state (na > 0)
+
 
 def _snapshot_state(data: Any) -> StateSnapshot:
-    return {
-        "qpos": np.array(data.qpos),
-        "qvel": np.array(data.qvel),
-        "act": np.array(data.act) if hasattr(data, "act") else None,
-        "ctrl": np.array(data.ctrl),
-        "time": np.array(data.time, dtype=float).copy(),
-    }
+    snap: StateSnapshot = {name: np.array(getattr(data, name)) for name in _FIELDS}
+    for name in _OPTIONAL:
+        snap[name] = np.array(getattr(data, name)) if hasattr(data, name) else None
+    snap["time"] = np.array(data.time, dtype=float).copy()
+    return snap
 
 
 def _restore_state(data: Any, snap: StateSnapshot) -> None:
-    data.qpos[...] = snap["qpos"]
-    data.qvel[...] = snap["qvel"]
-    data.ctrl[...] = snap["ctrl"]
-    t = snap.get("time")
-    data.time = 0.0 if t is None else (float(t) if np.ndim(t) == 0 else np.asarray(t, dtype=float))
+    for name in _FIELDS:
+        getattr(data, name)[...] = snap[name]
+    when = snap.get("time")
+    if when is None:
+        data.time = 0.0
+    else:
+        data.time = float(when) if np.ndim(when) == 0 else np.asarray(when, dtype=float)
 
 
 __all__ = ["_snapshot_state", "_restore_state"]
