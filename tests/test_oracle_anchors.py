@@ -100,13 +100,11 @@ def test_k3b_cartpole_slider_limit_engages(oracle):
 def test_k4_drone_free_fall_and_unit_quaternion(oracle, tmp_path, models):
     """Without the fluid (density = viscosity = 0) a tumbling drone is in exact free fall; with the fluid it is slower."""
     import os
-    import shutil
 
     src = os.path.dirname(models["drone2"])
-    for f in ("scene.xml", "x2.xml"):
-        shutil.copy(os.path.join(src, f), tmp_path / f)
-    x2 = (tmp_path / "x2.xml").read_text().replace('density="1.225" viscosity="1.8e-5"', "")
-    (tmp_path / "x2.xml").write_text(x2)
+    # fresh files (not copies: a read-only source tree would hand its permission bits to the copy)
+    (tmp_path / "scene.xml").write_text(open(os.path.join(src, "scene.xml")).read())
+    (tmp_path / "x2.xml").write_text(open(os.path.join(src, "x2.xml")).read().replace('density="1.225" viscosity="1.8e-5"', ""))
     cm = mjcf.compile_xml_path(str(tmp_path / "scene.xml"))
     assert cm.density == 0 and cm.viscosity == 0
     vac = mjo.OracleData(mjo.OracleModel(cm))
