@@ -146,7 +146,7 @@ def compile_spec(source: str, *, force: bool = False) -> str:
     import subprocess
 
     extra = os.environ.get("MJB_SPEC_FLAGS", "").split()        # experiments, e.g. -DMJB_WPS=3 (register budget for 3 waves/SIMD)
-    h = hashlib.sha1((source + " ".join(extra)).encode())
+    h = hashlib.sha1((source + " ".join(extra) + " sched=iterative-ilp").encode())
     for f in ("mjb_types.hpp", "mjb_device.hpp", "mjb_kernels.hpp"):
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -180,13 +180,24 @@ def compile_spec(source: str, *, force: bool = False) -> str:
     except OSError as exc:
         raise TemplateError(f"cannot write the specialised kernel source: {exc}") from exc
     tmp = out + f".tmp{os.getpid()}"
-    cmd = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", *extra, "-I", _CSRC, "-o", tmp, src]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    except (OSError, subprocess.SubprocessError) as exc:
-        raise TemplateError(f"hipcc could not be run: {exc}") from exc
-    if r.returncode != 0 or not os.path.exists(tmp):
-        raise TemplateError("specialised kernel failed to compile:\n" + r.stderr[-2000:])
+    base = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on"]
+    tail = [*extra, "-I", _CSRC, "-o", tmp, src]
+    # the iterative ILP scheduler is worth ~4 % on the humanoid but has been seen to crash the compiler on tiny models:
+    # try it first, fall back to the default scheduler (same arithmetic either way)
+    attempts = ([*base, "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *tail], [*base, *tail])
+    err = ""
+    for cmd in attempts:
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.SubprocessError) as exc:
+            raise TemplateError(f"hipcc could not be run: {exc}") from exc
+        if r.returncode == 0 and os.path.exists(tmp):
+            break
+        err = r.stderr
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    else:
+        raise TemplateError("specialised kernel failed to compile:\n" + err[-2000:])
     os.replace(tmp, out)
     return out
 
