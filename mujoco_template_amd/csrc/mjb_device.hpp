@@ -1042,7 +1042,7 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
     const int jadr = m.body_irec[4 * b], jnum = m.body_irec[4 * b + 1], jt0 = m.body_irec[4 * b + 2];
     T pos[3], quat[4], R[9];
     if (jnum == 1 && jt0 == JNT_FREE) {
-      int qa = m.jnt_irec[2 * jadr + 1];
+      int qa = m.jnt_irec[6 * jadr + 1];
       quat[0] = qpos[qa + 3]; quat[1] = qpos[qa + 4]; quat[2] = qpos[qa + 5]; quat[3] = qpos[qa + 6];
       quat_normalize(quat);
       qpos[qa + 3] = quat[0]; qpos[qa + 4] = quat[1]; qpos[qa + 5] = quat[2]; qpos[qa + 6] = quat[3];
@@ -1057,7 +1057,7 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
       for (int j = jadr; j < jadr + jnum; j++) {
         T jp[3] = {m.jnt_rec[8 * j], m.jnt_rec[8 * j + 1], m.jnt_rec[8 * j + 2]};
         T ja[3] = {m.jnt_rec[8 * j + 3], m.jnt_rec[8 * j + 4], m.jnt_rec[8 * j + 5]};
-        const int jtype = m.jnt_irec[2 * j], qa = m.jnt_irec[2 * j + 1];
+        const int jtype = m.jnt_irec[6 * j], qa = m.jnt_irec[6 * j + 1];
         T val = qpos[qa] - m.jnt_rec[8 * j + 6];
         T anchor[3], axis[3];
         quat2mat(R, quat);
@@ -1127,8 +1127,8 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
     for (int k = 0; k < 9; k++) { xmat[9 * b + k] = R[k]; ximat[9 * b + k] = R2[k]; }
   }
   for (int j = lane; j < m.njnt; j += G) {
-    if (m.jnt_type[j] == JNT_FREE) continue;                    // already world values (the parent is the world body)
-    int p = m.body_parentid[m.jnt_bodyid[j]];
+    if (m.jnt_irec[6 * j] == JNT_FREE) continue;                // already world values (the parent is the world body)
+    int p = m.jnt_irec[6 * j + 4];
     T pq[4], R[9], a[3], ax[3], la[3] = {xanchor[3 * j], xanchor[3 * j + 1], xanchor[3 * j + 2]}, lx[3] = {xaxis[3 * j], xaxis[3 * j + 1], xaxis[3 * j + 2]};
 #pragma unroll
     for (int k = 0; k < 4; k++) pq[k] = xquat[4 * p + k];
@@ -1204,7 +1204,7 @@ template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
   }
   T *cdof = w + L.cdof, *xanchor = w + L.xanchor, *xaxis = w + L.xaxis;
   for (int j = lane; j < m.njnt; j += G) {
-    int b = m.jnt_bodyid[j], da = m.jnt_dofadr[j], r = m.body_rootid[b], jt = m.jnt_type[j];
+    int b = m.jnt_irec[6 * j + 3], da = m.jnt_irec[6 * j + 2], r = m.jnt_irec[6 * j + 5], jt = m.jnt_irec[6 * j];
     T off[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) off[k] = sc[3 * r + k] - xanchor[3 * j + k];
@@ -1726,15 +1726,14 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
   gsync<G>();
   tree_forward_sum<T, G, 6>(c, cvel);
   for (int j = lane; j < nv; j += G) {
-    int b = m.dof_bodyid[j], p = m.body_parentid[b], jn = m.dof_jntid[j], jd = m.jnt_dofadr[jn];
-    const bool isfree = m.jnt_type[jn] == JNT_FREE;
+    const int p = m.dof_irec[6 * j + 1], first = m.dof_irec[6 * j + 2], gs = m.dof_irec[6 * j + 3];   // one record: no index hops
     T tmp[6] = {0, 0, 0, 0, 0, 0};
-    if (!(isfree && j < jd + 3)) {                              // translational dofs of a free joint: cdof_dot = 0
-      const int gs = isfree ? jd + 3 : j;                       // the three rotations of a free joint share the velocity after its translations
+    if (gs >= 0) {                                              // gs < 0: translational dof of a free joint, cdof_dot = 0
+      // gs: the three rotations of a free joint share the velocity after its translations; every other dof starts at itself
       T cv[6], cd[6];
 #pragma unroll
       for (int q = 0; q < 6; q++) { cv[q] = cvel[6 * p + q]; cd[q] = cdof[6 * j + q]; }
-      for (int k = m.body_dofadr[b]; k < gs; k++) {
+      for (int k = first; k < gs; k++) {
         T qv = qvel[k];
 #pragma unroll
         for (int q = 0; q < 6; q++) cv[q] += cdof[6 * k + q] * qv;
@@ -1823,16 +1822,13 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
   }
   T *qb = w + L.qfrc_bias, *qp = w + L.qfrc_passive;
   for (int i = lane; i < nv; i += G) {
-    int b = m.dof_bodyid[i], j = m.dof_jntid[i], jt = m.jnt_type[j];
+    const int b = m.dof_irec[6 * i], qa = m.dof_irec[6 * i + 4];
     T v = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) v += cdof[6 * i + k] * cfrc[6 * b + k];
     qb[i] = v;
-    T pf = -m.dof_damping[i] * qvel[i];
-    if ((jt == JNT_HINGE || jt == JNT_SLIDE) && m.jnt_stiffness[j] != 0) {
-      int qa = m.jnt_qposadr[j];
-      pf -= m.jnt_stiffness[j] * (qpos[qa] - m.qpos_spring[qa]);
-    }
+    T pf = -m.dof_frec[4 * i] * qvel[i];
+    if (qa >= 0) pf -= m.dof_frec[4 * i + 1] * (qpos[qa] - m.dof_frec[4 * i + 2]);      // hinge / slide spring
     if (m.has_fluid) {
       T* xipos = w + L.xipos;
       for (int bb = 1; bb < m.nbody; bb++) {
@@ -2169,8 +2165,8 @@ template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
 // A16 position integration for the joints of one environment (lanes over joints)
 template <typename T, int G> MJB_DEV void integrate_pos(ModelRef<T> m, T* qpos, const T* qvel, T h, int lane) {
   for (int j = lane; j < m.njnt; j += G) {
-    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-    if (m.jnt_type[j] == JNT_FREE) {
+    int qa = m.jnt_irec[6 * j + 1], da = m.jnt_irec[6 * j + 2];
+    if (m.jnt_irec[6 * j] == JNT_FREE) {
       qpos[qa] += h * qvel[da]; qpos[qa + 1] += h * qvel[da + 1]; qpos[qa + 2] += h * qvel[da + 2];
       T q[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]}, wv[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]};
       quat_integrate(q, wv, h);

@@ -313,11 +313,29 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
     // kinematics records
     const auto& jp = h.D("jnt_pos"); const auto& ja = h.D("jnt_axis"); const auto& q0 = h.D("qpos0");
     std::vector<T> jrec((size_t)h.njnt * 8, (T)0);
-    std::vector<int> jirec((size_t)h.njnt * 2, 0);
+    std::vector<int> jirec((size_t)h.njnt * 6, 0);
+    const auto& jb = h.I("jnt_bodyid"); const auto& bpar = h.I("body_parentid"); const auto& broot = h.I("body_rootid");
     for (int j = 0; j < h.njnt; j++) {
       for (int k = 0; k < 3; k++) { jrec[8 * j + k] = (T)jp[3 * j + k]; jrec[8 * j + 3 + k] = (T)ja[3 * j + k]; }
       jrec[8 * j + 6] = (T)q0[jq[j]];
-      jirec[2 * j] = jt[j]; jirec[2 * j + 1] = jq[j];
+      int* r = &jirec[6 * j];
+      r[0] = jt[j]; r[1] = jq[j]; r[2] = jd[j]; r[3] = jb[j]; r[4] = bpar[jb[j]]; r[5] = broot[jb[j]];
+    }
+    {
+      const auto& db = h.I("dof_bodyid"); const auto& dj = h.I("dof_jntid"); const auto& bda = h.I("body_dofadr");
+      const auto& dd = h.D("dof_damping"); const auto& js = h.D("jnt_stiffness"); const auto& qs = h.D("qpos_spring");
+      std::vector<int> dir((size_t)h.nv * 6, 0);
+      std::vector<T> dfr((size_t)h.nv * 4, (T)0);
+      for (int i = 0; i < h.nv; i++) {
+        const int b = db[i], j = dj[i], type = jt[j], first = jd[j];
+        int* r = &dir[6 * i];
+        r[0] = b; r[1] = bpar[b]; r[2] = bda[b];
+        r[3] = type == JNT_FREE ? (i < first + 3 ? -1 : first + 3) : i;
+        const bool spring = (type == JNT_HINGE || type == JNT_SLIDE) && js[j] != 0;
+        r[4] = spring ? jq[j] : -1;
+        dfr[4 * i] = (T)dd[i]; dfr[4 * i + 1] = (T)(spring ? js[j] : 0.0); dfr[4 * i + 2] = (T)(spring ? qs[jq[j]] : 0.0);
+      }
+      m.dof_irec = (IP)alloc.puti(dir); m.dof_frec = (FP)alloc.putf(dfr);
     }
     const auto& bja = h.I("body_jntadr"); const auto& bjn = h.I("body_jntnum");
     std::vector<int> birec((size_t)h.nbody * 4, 0);

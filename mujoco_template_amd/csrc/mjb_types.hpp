@@ -68,7 +68,9 @@ struct DevModel {
   FP pair_kb;        // per pair: margin - gap, body_invweight0 sum (translational), K, B of the contact rows (all model constants)
   FP lim_f;          // per limit object (joints, then tendons) x 12: range lo/hi, margin, diagApprox, K, B, solimp[5], pad
   FP jnt_rec;        // per joint x 8: jnt_pos[3], jnt_axis[3], qpos0[jnt_qposadr], pad   (kinematics: one record, no second hop)
-  IP jnt_irec;       // per joint x 2: type, qposadr
+  IP jnt_irec;       // per joint x 6: type, qposadr, dofadr, body, parent of that body, root of that body
+  IP dof_irec;       // per dof x 6: body, parent of that body, first dof of the body, dof where its velocity group starts (-1: translational dof of a free joint), qpos address of its spring (-1: none), pad
+  FP dof_frec;       // per dof x 4: damping, spring stiffness (0 when not a hinge/slide spring), qpos_spring of that address, pad
   IP body_irec;      // per body x 4: jntadr, jntnum, type of the first joint (-1 if none), pad
   IP pair_body;      // per pair x 2: bodies of geom1 / geom2 (folds geom_bodyid[pair_geom*])
   IP lim_i;          // per limit object x 2: limited-and-limitable flag, index of the value (qpos address / tendon id)
