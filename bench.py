@@ -7,7 +7,10 @@ Workload (config[2] of BASELINE.json, the one the metric is quoted on): the refe
 (qpos ‖ qvel, the default ObservationSpec of Env.from_xml_path) all-gathered over RCCL once
 per fused chunk.  One bench "step" = one simulation step of the whole global batch.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched under torchrun)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 from a plain shell: this process starts the N ranks itself as a child ``torch.distributed.run`` (before importing
+torch or touching HIP) and forwards rank 0's line; under torchrun (RANK / WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line (rank 0).  ``value`` = env-steps / s of the whole job with inputs resident
 in HBM; ``roofline`` prices the dominant kernel (k_step) against HBM with the algorithmic
@@ -29,6 +32,70 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def launcher_needed(gpus: int, environ) -> bool:
+    """True when this process must start the ranks itself: more than one GPU asked for and no torchrun environment present."""
+    return int(gpus) > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def launcher_command(gpus: int, argv: list[str], port: int) -> list[str]:
+    """The child command: ``torch.distributed.run`` (one rank per GPU) re-running THIS file with the same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def visible_gpu_count() -> int:
+    """Number of AMD GPUs the kernel driver exposes, counted WITHOUT touching HIP (the launcher must stay GPU-free):
+    KFD topology nodes with a non-zero SIMD count, narrowed by HIP/ROCR_VISIBLE_DEVICES when set.  -1 = unknown."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([t for t in v.split(",") if t.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(base):
+        return -1
+    n = 0
+    for node in os.listdir(base):
+        try:
+            props = open(os.path.join(base, node, "properties")).read()
+        except OSError:
+            return -1           # topology not readable by this user: let the ranks themselves report a missing device
+        for line in props.splitlines():
+            if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                n += 1
+    return n
+
+
+def launch_ranks(gpus: int, argv: list[str], all_ranks_device0: bool = False) -> int:
+    """Run the N ranks as a child ``torch.distributed.run`` and forward rank 0's JSON line; returns the exit code."""
+    import socket
+    import subprocess
+
+    if not all_ranks_device0:
+        have = visible_gpu_count()
+        if 0 <= have < gpus:
+            print(f"bench.py: --gpus {gpus} but only {have} GPU(s) are visible on this machine", file=sys.stderr)
+            return 2
+    with socket.socket() as s:          # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(launcher_command(gpus, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +113,11 @@ def main() -> None:
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    if launcher_needed(args.gpus, os.environ):
+        # `python bench.py --gpus N` from a plain shell: start the N ranks as CHILD processes before this process imports torch or
+        # makes any HIP call (never os.exec*, never a relaunch from a process that has touched the GPU); forward rank 0's line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], all_ranks_device0=args.all_ranks_device0))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -55,8 +127,10 @@ def main() -> None:
 
     rank, ws, local = world()
     if ws != args.gpus:
-        if rank == 0 and ws > 1:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={ws}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: start it as `python bench.py --gpus N` (it launches its own "
+                         "ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus")
+    if not args.all_ranks_device0 and torch.cuda.device_count() < (local + 1 if ws > 1 else 1):
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local} but only {torch.cuda.device_count()} device(s) are visible")
     if args.all_ranks_device0 and args.backend == "nccl":
         raise SystemExit("--all-ranks-device0 needs --backend gloo (RCCL refuses two ranks on one GPU)")
     device = 0 if (ws == 1 or args.all_ranks_device0) else local
@@ -82,11 +156,13 @@ def main() -> None:
     sim.use_torch_stream()
     obs_dim = env.extractor.obs_dim
     nq, nv, nu = env.model.nq, env.model.nv, env.model.nu
+    # steps fused per launch: --chunk, but never fewer than 5 timed launches (a short --steps run is then not one single launch)
+    chunk = max(1, min(args.chunk, -(-args.steps // 5)))
 
     def run(nsteps: int, events=None) -> None:
         done = 0
         while done < nsteps:
-            n = min(args.chunk, nsteps - done)
+            n = min(chunk, nsteps - done)
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -117,6 +193,13 @@ def main() -> None:
     counters = env.data.counters()
     kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     steps_per_launch = [n for _, _, n in events]
+    ranks_seen = dist.get_world_size() if distributed else 1
+    shards = [[env0, count]]
+    if distributed:
+        mine = torch.tensor([env0, count], device=f"cuda:{device}" if args.backend == "nccl" else "cpu", dtype=torch.int64)
+        got = [torch.zeros_like(mine) for _ in range(ws)]
+        dist.all_gather(got, mine)
+        shards = [[int(g[0]), int(g[1])] for g in got]
 
     if rank == 0:
         value = global_batch * args.steps / elapsed
@@ -127,18 +210,24 @@ def main() -> None:
         avg_steps = float(np.mean(steps_per_launch))
         launch_bytes = count * (bytes_step * avg_steps + bytes_obs)          # one obs row per env per launch
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None          # HBM bytes per launch from the committed PMC profile of this same command (separate --pmc passes)
+        # HBM bytes per launch from the committed PMC profiles (separate --pmc passes, profiles/traffic.json): only a record measured
+        # with the SAME model, batch and steps per launch as the launches timed here is quoted; anything else is null
+        traffic = traffic_source = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            rec = json.load(open(prof))
-            if rec.get("global_batch") == global_batch and rec.get("chunk") == args.chunk and ws == 1 and args.model == rec.get("model"):
-                traffic = rec.get("traffic_bytes_per_launch")
+        if os.path.exists(prof) and ws == 1 and len(set(steps_per_launch)) == 1:
+            recs = json.load(open(prof))
+            for rec in recs if isinstance(recs, list) else [recs]:
+                if (rec.get("model") == args.model and rec.get("global_batch") == global_batch
+                        and rec.get("launch_steps", rec.get("chunk")) == steps_per_launch[0]):
+                    traffic, traffic_source = rec.get("traffic_bytes_per_launch"), rec.get("source")
         out = {
             "metric": "env-steps/sec (whole node), humanoid batch=4096 random-ctrl rollout" if args.model == "humanoid"
                       else f"env-steps/sec (whole node), {args.model} random-ctrl rollout",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": ws,
+            "ranks_seen": ranks_seen,
+            "shards_env0_count": shards,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
@@ -151,11 +240,12 @@ def main() -> None:
             "config": {"workload": f"examples/{args.model} random-ctrl rollout (BASELINE.json configs[2])" if args.model == "humanoid"
                        else f"examples/{args.model} random-ctrl rollout",
                        "global_batch": global_batch, "per_gpu_batch": count, "rollout_steps": args.steps,
-                       "fused_steps_per_launch": args.chunk, "obs_dim": obs_dim, "parallelism": f"env-shard x{ws}",
+                       "fused_steps_per_launch": chunk, "obs_dim": obs_dim, "parallelism": f"env-shard x{ws}",
                        "lanes_per_env": sim.lanes, "lds_bytes_per_env": sim.lds_bytes_per_env,
                        "nefcmax": sim.nefcmax, "nconmax": sim.nconmax, "specialized_kernel": bool(sim.specialized)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("mjb_k_step_spec (k_step<float,float,%d> with the model's sizes/offsets folded in)" if sim.specialized else "mjb::k_step<float,float,%d>") % sim.lanes,
+                         "traffic_source": traffic_source, "launch_steps": avg_steps, "launches_timed": len(kernel_ms),
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_env_step": bytes_step, "obs_bytes_per_env": bytes_obs,
                          "note": "fused step is VALU/LDS-latency bound by construction (SURVEY.md §8d); see DESIGN.md for VALU/LDS counters"},
             "solver": {"mean_nefc_last_step": float(counters["nefc"].mean()), "max_nefc_last_step": int(counters["nefc"].max()),

@@ -163,3 +163,32 @@ def test_recorder_schema_and_trajectory_logger(tmp_path):
     assert path.read_text().splitlines() == ["a,b", "3,6"]
     with pytest.raises(ConfigError):
         TrajectoryLogger(None, (), lambda r: ())
+
+
+def test_bench_launcher_decision(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell starts its own N ranks as children (VERDICT r1 #1); under torchrun it is a rank."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert "torch" not in vars(bench)                                       # the launcher stays GPU- and torch-free at import
+    assert not bench.launcher_needed(1, {})
+    assert bench.launcher_needed(2, {})
+    assert bench.launcher_needed(8, {"HOME": "/x"})
+    assert not bench.launcher_needed(8, {"WORLD_SIZE": "8", "RANK": "3"})  # already one of torchrun's ranks
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "7"], 29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd and "29999" in cmd
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7"]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpu_count() == 2
+    assert bench.launch_ranks(4, ["--gpus", "4"]) == 2                       # refuses loudly: fewer devices than ranks, nothing started
+
+
+def test_bench_wrong_world_size_is_refused():
+    """A rank whose WORLD_SIZE differs from --gpus must not silently run a different job (the r1 bench printed n_gpus=1 for --gpus 8)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
