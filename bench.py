@@ -106,6 +106,7 @@ def main() -> None:
     ap.add_argument("--weak", action="store_true", help="fixed per-GPU batch (= --global-batch per rank) instead of sharding it")
     ap.add_argument("--model", default="humanoid", choices=["humanoid", "cartpole", "drone2", "pendulum"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-loop", action="store_true", help="skip the host-driven Env.passive measurement (Python controller in the loop)")
     ap.add_argument("--nefcmax", type=int, default=0)
     ap.add_argument("--nconmax", type=int, default=0)
     ap.add_argument("--no-specialize", action="store_true", help="use the generic step kernel instead of the per-model specialised one")
@@ -255,10 +256,78 @@ def main() -> None:
         }
         if ws == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, xml), scale)
+        if ws == 1 and not args.no_host_loop:
+            out["host_loop"] = host_loop(os.path.join(ROOT, xml), scale, device, global_batch)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class _HostRandomCtrl:
+    """A controller that lives in Python (no ``device_ctrl_mode``): the shape of every controller in the reference's examples —
+    read ``data``, write ``data.ctrl`` in place, once per step (reference control.py:26-32)."""
+
+    def __init__(self, scale: float, seed: int = 0):
+        import numpy as np
+
+        from mujoco_template_amd import ControllerCapabilities, ControlSpace
+
+        self.capabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
+        self.scale, self.rng = scale, np.random.default_rng(seed)
+
+    def prepare(self, model, data) -> None:
+        import numpy as np
+
+        lo = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 0], -1.0)
+        hi = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 1], 1.0)
+        self.mid, self.half = 0.5 * (lo + hi), 0.5 * (hi - lo) * self.scale
+
+    def __call__(self, model, data, t: float) -> None:
+        data.ctrl[...] = self.mid + self.half * self.rng.uniform(-1.0, 1.0, size=data.ctrl.shape)
+
+
+def host_loop(xml_path: str, scale: float, device: int, batch: int) -> dict:
+    """The reference's actual usage shape on this engine (reference runtime.py:631-663): ``Env.passive`` with a
+    PYTHON controller in the loop — one ``Env.step`` per step: controller call, edited mirrors up, one mj_step launch, the
+    pinned state block back (``mjb_step_host``), observation extraction.  Bounded samples, batch 1 and the bench batch."""
+    from mujoco_template_amd import Env, ObservationSpec
+
+    out: dict = {"unit": "env-steps/s", "controller": "python (numpy uniform ctrl written in place every step)",
+                 "path": "Env.passive -> Env.step -> mjb_step_host (packed H2D of edited fields + k_step(1) + packed D2H)"}
+    for b, nsteps in ((1, 400), (batch, 60)):
+        env = Env.from_xml_path(xml_path, obs_spec=ObservationSpec(as_dict=False), controller=_HostRandomCtrl(scale), batch=b,
+                                dtype="float32", device=device)
+        for return_obs in (True, False):
+            for _ in env.passive(max_steps=20, return_obs=return_obs):
+                pass
+            t = time.perf_counter()
+            for _ in env.passive(max_steps=nsteps, return_obs=return_obs):
+                pass
+            dt = time.perf_counter() - t
+            out[f"batch{b}_return_obs_{return_obs}"] = {"value": b * nsteps / dt, "us_per_step": dt / nsteps * 1e6, "steps": nsteps}
+        del env
+    return out
+
+
+def _oracle_passive_loop(om, mjo, scale: float, nsteps: int, return_obs: bool) -> float:
+    """The reference's loop shape on the CPU port: ONE interpreter-level physics call per step at batch 1, controller and
+    observation assembled in Python (reference runtime.py:631-663 / env.py:186-230).  Returns steps per second."""
+    import numpy as np
+
+    od = mjo.OracleData(om)
+    cm = om.compiled
+    rng = np.random.default_rng(0)
+    lo = np.where(cm.actuator_ctrllimited, cm.actuator_ctrlrange[:, 0], -1.0)
+    hi = np.where(cm.actuator_ctrllimited, cm.actuator_ctrlrange[:, 1], 1.0)
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo) * scale
+    t = time.perf_counter()
+    for _ in range(nsteps):
+        od.ctrl[:] = mid + half * rng.uniform(-1.0, 1.0, size=cm.nu)
+        od.step()
+        if return_obs:
+            np.concatenate([od.qpos, od.qvel])
+    return nsteps / (time.perf_counter() - t)
 
 
 def cpu_baseline(xml_path: str, scale: float) -> dict:
@@ -276,8 +345,13 @@ def cpu_baseline(xml_path: str, scale: float) -> dict:
     t1 = time.perf_counter()
     mjo.rollout_batch(om, 16, nstep, seed=0, scale=scale, nthreads=1)
     dt1 = time.perf_counter() - t1
+    _oracle_passive_loop(om, mjo, scale, 200, True)           # warm-up
+    loop = {f"return_obs_{ro}": _oracle_passive_loop(om, mjo, scale, 20000, ro) for ro in (True, False)}
     return {"value": nenv * nstep / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "single_core_value": 16 * nstep / dt1,
+            "loop_faithful": {"unit": "env-steps/s", "cores": 1, **loop,
+                              "what": "the reference's loop shape (runtime.py:631-663): batch 1, one Python-level physics call per step, "
+                                      "Python controller + observation, 20000 steps; physics = the float64 C oracle"},
             "sample": f"{nenv} envs x {nstep} steps of the same random-ctrl rollout, float64 C oracle, one env per OpenMP task; "
                       "the reference's own CPU loop (mujoco wheel) is not runnable here"}
 

@@ -44,7 +44,7 @@ int mjb_device_count(void);
 
 /* ---- model: replaces MjModel.from_xml_* (reference model.py:22-37).  The XML is compiled on the
  * host by mujoco_template_amd/mjcf.py; the compiled model crosses the ABI as a table of named
- * arrays (dtype 0 = float64, 1 = int32) whose names follow mjModel. ---- */
+ * arrays (dtype 0 = float64, 1 = int32, 2 = bytes) whose names follow mjModel. ---- */
 int mjb_model_create(int nfield, const char* const* names, const void* const* ptrs, const int* dtypes,
                      const long* counts, mjbModel** out);
 void mjb_model_free(mjbModel* m);
@@ -52,6 +52,29 @@ void mjb_model_free(mjbModel* m);
 int mjb_model_set_disableactuator(mjbModel* m, int mask);
 /* solver knobs (mjOption.iterations / tolerance) */
 int mjb_model_set_solver(mjbModel* m, int iterations, double tolerance);
+
+/* object names: mj_name2id / mj_id2name (reference observations.py:80-84, jacobians.py:39-75, logging.py:88-126, model.py:64).
+ * objtype = MuJoCo's mjtObj code (1 body, 2 xbody, 3 joint, 5 geom, 6 site, 18 tendon, 19 actuator, 20 sensor, 24 key);
+ * name2id returns -1 when the name is unknown (the host front raises NameLookupError), id2name NULL for unnamed / out of range.
+ * The names cross mjb_model_create as table fields "names_<objtype>" of dtype 2 (bytes: NUL-terminated names in id order). */
+int mjb_model_name2id(const mjbModel* m, int objtype, const char* name);
+const char* mjb_model_id2name(const mjbModel* m, int objtype, int id);
+/* any field of the compiled model by its mjModel name ("nq", "nv", "actuator_ctrlrange", "jnt_type", ...): host pointer valid for the
+ * model's lifetime, element count and dtype (0 float64, 1 int32, 2 bytes) — the model.nq / model.actuator_* / model.jnt_* attribute
+ * reads of the reference (mujoco.pyi:7-49, compat.py:64-121) for a host that is not Python */
+int mjb_model_field(const mjbModel* m, const char* name, const void** ptr, long* count, int* dtype);
+/* enumeration of the same fields: 0 and the field's name / pointer / count / dtype for 0 <= index < n, otherwise n (the field count) */
+int mjb_model_field_at(const mjbModel* m, int index, const char** name, const void** ptr, long* count, int* dtype);
+/* MjModel.from_binary_path / mj_saveModel (reference model.py:28-31, :49): the compiled table in a flat binary file ("MJBM0001").
+ * A host without the Python MJCF compiler loads a model compiled once elsewhere. */
+int mjb_model_save(const mjbModel* m, const char* path);
+int mjb_model_load(const char* path, mjbModel** out);
+
+/* mj_integratePos(m, qpos, qvel, dt) / mj_differentiatePos(m, qvel, dt, qpos1, qpos2) (reference linearization.py:12,67,77,
+ * examples/humanoid/controllers/lqr.py:153, examples/drone2/main.py:404-406): in place on CALLER-OWNED HOST vectors, float64,
+ * batched: qpos [batch, nq], qvel [batch, nv] row-major.  qvel_out = (qpos2 (-) qpos1) / dt in the tangent space. */
+int mjb_integrate_pos(const mjbModel* m, int batch, double* qpos, const double* qvel, double dt);
+int mjb_differentiate_pos(const mjbModel* m, int batch, double* qvel_out, double dt, const double* qpos1, const double* qpos2);
 
 /* ---- data: replaces MjData(model) (reference model.py:16-19) for `batch` independent replicas.
  * dtype: MJB_F32 (product path) or MJB_F64.  lanes: lanes per environment (8, 16, 64; 0 = auto).
@@ -70,6 +93,21 @@ int mjb_array_ptr(mjbData* d, const char* name, void** dev_ptr, long* per_env, i
 int mjb_get_array(mjbData* d, const char* name, double* host_out);
 int mjb_set_array(mjbData* d, const char* name, const double* host_in);
 int mjb_get_counters(mjbData* d, int* host_out /* [batch, 8] */);
+
+/* ---- host mirror ("host_view"): the zero-copy numpy views data.qpos / qvel / ctrl / qacc / qacc_warmstart / time of the reference
+ * (mujoco.pyi:51-75; observations with copy=False alias them, tests/test_mujoco_template.py:241-252) as ONE pinned float64 block
+ * per data object.  mjb_host_view returns the address of one field's [batch, n] slice (valid for the data's lifetime);
+ * mjb_sync_to_host refreshes the whole block with one pack kernel + ONE device-to-host copy + one stream sync;
+ * mjb_sync_to_device uploads the fields named in field_mask (bit 0 qpos, 1 qvel, 2 ctrl, 3 qacc, 4 qacc_warmstart, 5 time) after the
+ * host edited them in place (data.ctrl[:] = ..., what every reference controller does);
+ * mjb_step_host = sync_to_device(field_mask) + nstep x mj_step (nstep = 0: mj_forward) + sync_to_host in one call: the body of the
+ * reference's host-driven loop (env.py:186-190, runtime.py:631-663) costs one library call per step. ---- */
+/* name "engine_flags": ONE double behind the state, refreshed by the same copy: sticky bits 0 contacts dropped, 1 constraint rows dropped
+ * (per-environment LDS caps exceeded), 2 bad-state auto-reset — the whole-batch OR of what mjb_get_counters details per environment */
+int mjb_host_view(mjbData* d, const char* name, double** host_ptr, long* per_env);
+int mjb_sync_to_host(mjbData* d);
+int mjb_sync_to_device(mjbData* d, int field_mask);
+int mjb_step_host(mjbData* d, int nstep, int field_mask);
 
 /* ---- per-model specialisation of the fp32 step kernel (no reference counterpart: the reference's MjModel is interpreted by
  * one pre-built C library; here the structural sizes of the compiled model and the LDS layout offsets can be folded into the

@@ -89,10 +89,27 @@ def load_library() -> ctypes.CDLL:
     L.mjb_profile_get.restype = ci
     L.mjb_debug_forward.argtypes = [vp]
     L.mjb_debug_get.argtypes = [vp, ctypes.c_char_p, vp, cl]
+    pcl = ctypes.POINTER(cl)
+    L.mjb_model_name2id.argtypes = [vp, ci, ctypes.c_char_p]
+    L.mjb_model_name2id.restype = ci
+    L.mjb_model_id2name.argtypes = [vp, ci, ci]
+    L.mjb_model_id2name.restype = ctypes.c_char_p
+    L.mjb_model_field.argtypes = [vp, ctypes.c_char_p, pvp, pcl, pci]
+    L.mjb_model_field_at.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), pvp, pcl, pci]
+    L.mjb_model_save.argtypes = [vp, ctypes.c_char_p]
+    L.mjb_model_load.argtypes = [ctypes.c_char_p, pvp]
+    L.mjb_integrate_pos.argtypes = [vp, ci, vp, vp, cd]
+    L.mjb_differentiate_pos.argtypes = [vp, ci, vp, cd, vp, vp]
+    L.mjb_host_view.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.POINTER(cd)), pcl]
+    L.mjb_sync_to_host.argtypes = [vp]
+    L.mjb_sync_to_device.argtypes = [vp, ci]
+    L.mjb_step_host.argtypes = [vp, ci, ci]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
                  "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
-                 "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get"):
+                 "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get", "mjb_model_field", "mjb_model_field_at", "mjb_model_save",
+                 "mjb_model_load", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
+                 "mjb_step_host"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
@@ -110,6 +127,15 @@ class _CudaArray:
     def __init__(self, ptr: int, shape: tuple[int, ...], typestr: str, owner: object):
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
         self._owner = owner
+
+
+def _manifold_batch(arr: np.ndarray, n: int, what: str) -> int:
+    """Batch size of a caller-owned [n] / [batch, n] float64 vector the C side edits in place."""
+    if not isinstance(arr, np.ndarray) or arr.dtype != np.float64 or not arr.flags.c_contiguous or not arr.flags.writeable:
+        raise ConfigError(f"{what} must be a writeable C-contiguous float64 numpy array (it is modified in place)")
+    if n == 0 or arr.size % n or arr.ndim not in (1, 2) or arr.shape[-1] != n:
+        raise ConfigError(f"{what} must have shape [{n}] or [batch, {n}]")
+    return arr.size // n
 
 
 def _ids(seq: Sequence[int]):
@@ -220,17 +246,79 @@ class ObsSpecHandle:
             pass
 
 
+MIRROR_FIELDS = ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "time")     # bit order of the field masks of mjb_sync_to_device / mjb_step_host
+
+
 class DeviceModel:
     """Handle of ``mjbModel`` (host copy of the compiled model inside the library)."""
 
-    def __init__(self, compiled: CompiledModel):
+    def __init__(self, compiled: CompiledModel | None, *, _ptr: ctypes.c_void_p | None = None):
         L = load_library()
+        if _ptr is not None:                                   # adopted handle (DeviceModel.load)
+            self.ptr, self._packed = _ptr, None
+            self.compiled = self._compiled_from_library()
+            return
         self.compiled = compiled
         self._packed = PackedTable(compiled)
         p = self._packed
         self.ptr = ctypes.c_void_p()
         _check(L.mjb_model_create(p.n, ctypes.cast(p.names, ctypes.c_void_p), ctypes.cast(p.ptrs, ctypes.c_void_p),
                                   ctypes.cast(p.dtypes, ctypes.c_void_p), ctypes.cast(p.counts, ctypes.c_void_p), ctypes.byref(self.ptr)))
+
+    # -- MjModel.from_binary_path / mj_saveModel (reference model.py:28-31,:49) -----------------------
+    @classmethod
+    def load(cls, path: str) -> "DeviceModel":
+        ptr = ctypes.c_void_p()
+        _check(load_library().mjb_model_load(os.fsencode(path), ctypes.byref(ptr)))
+        return cls(None, _ptr=ptr)
+
+    def save(self, path: str) -> None:
+        _check(load_library().mjb_model_save(self.ptr, os.fsencode(path)))
+
+    def fields(self) -> dict[str, np.ndarray]:
+        """Every field of the model table as a numpy copy (``mjb_model_field_at``)."""
+        L = load_library()
+        out: dict[str, np.ndarray] = {}
+        name, ptr, cnt, dt = ctypes.c_char_p(), ctypes.c_void_p(), ctypes.c_long(), ctypes.c_int()
+        i = 0
+        while L.mjb_model_field_at(self.ptr, i, ctypes.byref(name), ctypes.byref(ptr), ctypes.byref(cnt), ctypes.byref(dt)) == 0:
+            ctype, npdt = {0: (ctypes.c_double, np.float64), 1: (ctypes.c_int, np.int32), 2: (ctypes.c_ubyte, np.uint8)}[dt.value]
+            n = int(cnt.value)
+            out[name.value.decode()] = (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=(n,)).astype(npdt, copy=True)
+                                        if n else np.zeros(0, dtype=npdt))
+            i += 1
+        return out
+
+    def _compiled_from_library(self) -> CompiledModel:
+        from ._pack import compiled_from_fields
+
+        return compiled_from_fields(self.fields())
+
+    # -- names (mj_name2id / mj_id2name) ----------------------------------------------------------------
+    def name2id(self, objtype: int, name: str) -> int:
+        return int(load_library().mjb_model_name2id(self.ptr, int(objtype), str(name).encode()))
+
+    def id2name(self, objtype: int, idx: int) -> str | None:
+        r = load_library().mjb_model_id2name(self.ptr, int(objtype), int(idx))
+        return r.decode() if r is not None else None
+
+    # -- position manifold (mj_integratePos / mj_differentiatePos), host float64, batched -------------
+    def integrate_pos(self, qpos: np.ndarray, qvel: np.ndarray, dt: float) -> None:
+        """In place on ``qpos`` ([nq] or [batch, nq], float64, C-contiguous)."""
+        batch = _manifold_batch(qpos, self.compiled.nq, "qpos")
+        v = np.ascontiguousarray(qvel, dtype=np.float64)
+        if v.size != batch * self.compiled.nv:
+            raise ConfigError("mj_integratePos: qvel must have nv entries per environment")
+        _check(load_library().mjb_integrate_pos(self.ptr, batch, qpos.ctypes.data, v.ctypes.data, float(dt)))
+
+    def differentiate_pos(self, qvel: np.ndarray, dt: float, qpos1: np.ndarray, qpos2: np.ndarray) -> None:
+        """``qvel <- (qpos2 (-) qpos1) / dt`` in place on ``qvel`` ([nv] or [batch, nv], float64, C-contiguous)."""
+        batch = _manifold_batch(qvel, self.compiled.nv, "qvel")
+        q1 = np.ascontiguousarray(qpos1, dtype=np.float64)
+        q2 = np.ascontiguousarray(qpos2, dtype=np.float64)
+        if q1.size != batch * self.compiled.nq or q2.size != q1.size:
+            raise ConfigError("mj_differentiatePos: qpos1 / qpos2 must have nq entries per environment")
+        _check(load_library().mjb_differentiate_pos(self.ptr, batch, qvel.ctypes.data, float(dt), q1.ctypes.data, q2.ctypes.data))
 
     def set_disableactuator(self, mask: int) -> None:
         _check(load_library().mjb_model_set_disableactuator(self.ptr, int(mask)))
@@ -345,6 +433,30 @@ class BatchSim:
         if n:
             _check(load_library().mjb_set_array(self.ptr, name.encode(), arr.ctypes.data))
 
+    # -- host mirror (mjb_host_view): pinned float64 block, one packed copy per direction ------------
+    def host_view(self, name: str) -> np.ndarray:
+        """numpy view [batch, n] over the library's pinned float64 mirror of ``name`` (valid while this object lives)."""
+        p, n = ctypes.POINTER(ctypes.c_double)(), ctypes.c_long()
+        _check(load_library().mjb_host_view(self.ptr, name.encode(), ctypes.byref(p), ctypes.byref(n)))
+        if name == "engine_flags":
+            return np.ctypeslib.as_array(p, shape=(1,))
+        if n.value == 0:
+            return np.zeros((self.batch, 0))
+        arr = np.ctypeslib.as_array(p, shape=(self.batch, int(n.value)))
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append(arr)
+        return arr
+
+    def sync_to_host(self) -> None:
+        _check(load_library().mjb_sync_to_host(self.ptr))
+
+    def sync_to_device(self, field_mask: int) -> None:
+        _check(load_library().mjb_sync_to_device(self.ptr, int(field_mask)))
+
+    def step_host(self, nstep: int, field_mask: int = 0) -> None:
+        """upload the edited mirror fields, ``nstep`` x mj_step (0: mj_forward), refresh the mirror — one library call."""
+        _check(load_library().mjb_step_host(self.ptr, int(nstep), int(field_mask)))
+
     def counters(self) -> dict[str, np.ndarray]:
         out = np.zeros((self.batch, 8), dtype=np.int32)
         _check(load_library().mjb_get_counters(self.ptr, out.ctypes.data))
@@ -430,4 +542,4 @@ class BatchSim:
             pass
 
 
-__all__ = ["BatchSim", "DeviceModel", "ObsSpecHandle", "build_library", "load_library", "CTRL_KEEP", "CTRL_ZERO", "CTRL_RANDOM", "CTRL_FEEDBACK"]
+__all__ = ["BatchSim", "DeviceModel", "ObsSpecHandle", "MIRROR_FIELDS", "build_library", "load_library", "CTRL_KEEP", "CTRL_ZERO", "CTRL_RANDOM", "CTRL_FEEDBACK"]

@@ -3,7 +3,9 @@
 // kernels of mjb_kernels.hpp on the caller's HIP stream.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -50,6 +52,10 @@ struct mjbModel {
   int disableactuator;
   int iterations;
   double tolerance;
+  std::vector<char> blob;                                   // the table this model was created from, serialised (mjb_model_save / mjb_model_field)
+  struct Field { std::string name; int dtype; long count; size_t off; };
+  std::vector<Field> fields;
+  std::map<int, std::vector<std::string>> names;            // object names by mjtObj code (table fields "names_<code>", dtype 2)
 };
 
 struct mjbObsSpec {
@@ -87,9 +93,71 @@ struct mjbData {
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   int* fd_valid = nullptr;
+  // host mirror (mjb_host_view): ONE pinned float64 block  qpos | qvel | ctrl | qacc | qacc_warmstart | time , each [batch, n],
+  // and its device staging twin; filled by one pack kernel + one D2H per mjb_sync_to_host
+  double *mirror_host = nullptr, *mirror_dev = nullptr;
+  size_t mirror_off[7] = {0, 0, 0, 0, 0, 0, 0};             // element offsets of the six fields, [6] = total
 };
 
 namespace {
+// ---- serialised model table: "MJBM0001", int32 nfield, then per field: int32 name length, name, int32 dtype (0 f64, 1 i32,
+// 2 bytes), int64 count, payload padded to 8 bytes.  Written by mjb_model_save, read by mjb_model_load; also what
+// mjb_model_field serves pointers into. ----
+size_t elem_size(int dtype) { return dtype == 0 ? 8 : (dtype == 1 ? 4 : 1); }
+bool keep_table(mjbModel* m, const Table& t, std::string& err) {
+  std::vector<char>& b = m->blob;
+  b.clear(); m->fields.clear(); m->names.clear();
+  auto put = [&](const void* p, size_t n) { const char* c = (const char*)p; b.insert(b.end(), c, c + n); };
+  put("MJBM0001", 8);
+  int32_t nf = t.n; put(&nf, 4);
+  for (int i = 0; i < t.n; i++) {
+    if (t.dtypes[i] < 0 || t.dtypes[i] > 2 || t.counts[i] < 0) { err = std::string("model field '") + t.names[i] + "': bad dtype/count"; return false; }
+    int32_t nl = (int32_t)std::strlen(t.names[i]), dt = t.dtypes[i]; int64_t cnt = t.counts[i];
+    put(&nl, 4); put(t.names[i], nl); put(&dt, 4); put(&cnt, 8);
+    while (b.size() % 8) b.push_back(0);
+    size_t off = b.size(), nb = (size_t)cnt * elem_size(dt);
+    if (nb) put(t.ptrs[i], nb);
+    while (b.size() % 8) b.push_back(0);
+    m->fields.push_back({t.names[i], dt, (long)cnt, off});
+    if (dt == 2 && !std::strncmp(t.names[i], "names_", 6)) {           // NUL-terminated names of one object type, in id order
+      std::vector<std::string>& v = m->names[std::atoi(t.names[i] + 6)];
+      const char* c = (const char*)t.ptrs[i];
+      for (long k = 0; k < cnt;) { size_t l = strnlen(c + k, (size_t)(cnt - k)); v.emplace_back(c + k, l); k += (long)l + 1; }
+    }
+  }
+  return true;
+}
+// parse a blob back into a Table (pointers into `b`)
+bool parse_blob(const std::vector<char>& b, std::vector<std::string>& names, std::vector<const void*>& ptrs, std::vector<int>& dts, std::vector<long>& cnts, std::string& err) {
+  size_t o = 0;
+  auto need = [&](size_t n) { return o + n <= b.size(); };
+  if (!need(12) || std::memcmp(b.data(), "MJBM0001", 8)) { err = "not a mjbatch model file (bad magic)"; return false; }
+  int32_t nf; std::memcpy(&nf, b.data() + 8, 4); o = 12;
+  if (nf < 0 || nf > 100000) { err = "corrupt model file (field count)"; return false; }
+  for (int i = 0; i < nf; i++) {
+    int32_t nl, dt; int64_t cnt;
+    if (!need(4)) { err = "truncated model file"; return false; }
+    std::memcpy(&nl, b.data() + o, 4); o += 4;
+    if (nl < 0 || nl > 256 || !need((size_t)nl + 12)) { err = "corrupt model file (field name)"; return false; }
+    names.emplace_back(b.data() + o, (size_t)nl); o += nl;
+    std::memcpy(&dt, b.data() + o, 4); o += 4; std::memcpy(&cnt, b.data() + o, 8); o += 8;
+    if (dt < 0 || dt > 2 || cnt < 0) { err = "corrupt model file (dtype/count)"; return false; }
+    o = (o + 7) / 8 * 8;
+    size_t nb = (size_t)cnt * elem_size(dt);
+    if (!need(nb)) { err = "truncated model file"; return false; }
+    ptrs.push_back(b.data() + o); dts.push_back(dt); cnts.push_back((long)cnt);
+    o = (o + nb + 7) / 8 * 8;
+  }
+  return true;
+}
+
+// the joints of one environment on the host, float64 (mj_integratePos / mj_differentiatePos act on caller-owned host vectors)
+void h_quat_mul(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+
 template <typename X> int dev_alloc(mjbData* d, X** out, size_t n) {
   void* p = nullptr;
   if (n == 0) n = 1;
@@ -111,7 +179,7 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   rc |= dev_alloc(d, &s.site_xpos, B * h.nsite * 3); rc |= dev_alloc(d, &s.geom_xpos, B * h.ngeom * 3);
   rc |= dev_alloc(d, &s.subtree_com, B * h.nbody * 3); rc |= dev_alloc(d, &s.sensordata, B * h.nsensordata);
   rc |= dev_alloc(d, &s.qfrc_inverse, B * h.nv); rc |= dev_alloc(d, &s.actuator_moment, B * h.nu * h.nv);
-  rc |= dev_alloc(d, &s.counters, B * CNT_N);
+  rc |= dev_alloc(d, &s.counters, B * CNT_N); rc |= dev_alloc(d, &s.flags, 1);
   rc |= dev_alloc(d, &s.prof, (size_t)PH_N);
   if (rc) return -1;
   auto& A = d->arrays;
@@ -152,6 +220,8 @@ int refresh_options(mjbData* d) {
   d->mf.disableactuator = d->md.disableactuator = mm->disableactuator;
   d->mf.iterations = d->md.iterations = mm->iterations;
   d->md.tolerance = mm->tolerance;
+  // fp32 floor of the solver tolerance: 1e-7 / 1e-8 were measured (profiles/r02_humanoid_phase_errors.log): +0.6 / +0.8 Newton
+  // iterations per step, -3 % / -4.5 % throughput, no change of the humanoid drift curve (the error enters through M and the bias force)
   float tol = (float)mm->tolerance;
   d->mf.tolerance = tol < 1e-6f ? 1e-6f : tol;
   HIPCHK(hipStreamSynchronize(d->stream));
@@ -267,6 +337,7 @@ int mjb_model_create(int nfield, const char* const* names, const void* const* pt
   mjbModel* m = new mjbModel();
   std::string err;
   if (!m->h.load(t, err)) { delete m; return fail(MJB_ERR_MODEL, err); }
+  if (!keep_table(m, t, err)) { delete m; return fail(MJB_ERR_MODEL, err); }
   m->disableactuator = m->h.disableactuator;
   m->iterations = m->h.iterations;
   m->tolerance = m->h.tolerance;
@@ -337,6 +408,7 @@ void mjb_data_free(mjbData* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : d->owned) (void)hipFree(p);
+  if (d->mirror_host) (void)hipHostFree(d->mirror_host);
   d->alloc.release();
   delete d;
 }
@@ -637,6 +709,222 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
   }
   (void)hipFree(op); (void)hipFree(orr); (void)hipFree(dk); (void)hipFree(di);
   return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// model: names, fields, binary save / load
+// ---------------------------------------------------------------------------------------------------------------------
+int mjb_model_name2id(const mjbModel* m, int objtype, const char* name) {
+  if (!m || !name) { fail(MJB_ERR_ARG, "model/name is NULL"); return -1; }
+  if (objtype == 2) objtype = 1;                                       // mjOBJ_XBODY aliases mjOBJ_BODY
+  auto it = m->names.find(objtype);
+  if (it == m->names.end()) return -1;
+  for (size_t i = 0; i < it->second.size(); i++) if (!it->second[i].empty() && it->second[i] == name) return (int)i;
+  return -1;
+}
+
+const char* mjb_model_id2name(const mjbModel* m, int objtype, int id) {
+  if (!m) { fail(MJB_ERR_ARG, "model is NULL"); return nullptr; }
+  if (objtype == 2) objtype = 1;
+  auto it = m->names.find(objtype);
+  if (it == m->names.end() || id < 0 || id >= (int)it->second.size() || it->second[id].empty()) return nullptr;
+  return it->second[id].c_str();
+}
+
+int mjb_model_field(const mjbModel* m, const char* name, const void** ptr, long* count, int* dtype) {
+  if (!m || !name) return fail(MJB_ERR_ARG, "model/name is NULL");
+  for (const auto& f : m->fields) if (f.name == name) {
+    if (ptr) *ptr = m->blob.data() + f.off;
+    if (count) *count = f.count;
+    if (dtype) *dtype = f.dtype;
+    return MJB_OK;
+  }
+  return fail(MJB_ERR_ARG, std::string("unknown model field: ") + name);
+}
+
+int mjb_model_field_at(const mjbModel* m, int index, const char** name, const void** ptr, long* count, int* dtype) {
+  if (!m) { fail(MJB_ERR_ARG, "model is NULL"); return -1; }
+  if (index < 0 || index >= (int)m->fields.size()) return (int)m->fields.size();     // out of range: returns the field count
+  const auto& f = m->fields[index];
+  if (name) *name = f.name.c_str();
+  if (ptr) *ptr = m->blob.data() + f.off;
+  if (count) *count = f.count;
+  if (dtype) *dtype = f.dtype;
+  return MJB_OK;
+}
+
+int mjb_model_save(const mjbModel* m, const char* path) {
+  if (!m || !path) return fail(MJB_ERR_ARG, "model/path is NULL");
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(MJB_ERR_ARG, std::string("cannot open for writing: ") + path);
+  size_t n = std::fwrite(m->blob.data(), 1, m->blob.size(), f);
+  int rc = std::fclose(f);
+  if (n != m->blob.size() || rc != 0) return fail(MJB_ERR_ARG, std::string("short write: ") + path);
+  return MJB_OK;
+}
+
+int mjb_model_load(const char* path, mjbModel** out) {
+  if (!path || !out) return fail(MJB_ERR_ARG, "path/out is NULL");
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(MJB_ERR_ARG, std::string("cannot open: ") + path);
+  std::vector<char> b;
+  char buf[65536];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + n);
+  std::fclose(f);
+  std::vector<std::string> names; std::vector<const void*> ptrs; std::vector<int> dts; std::vector<long> cnts;
+  std::string err;
+  if (!parse_blob(b, names, ptrs, dts, cnts, err)) return fail(MJB_ERR_MODEL, err + ": " + path);
+  std::vector<const char*> cn;
+  for (auto& s : names) cn.push_back(s.c_str());
+  return mjb_model_create((int)cn.size(), cn.data(), ptrs.data(), dts.data(), cnts.data(), out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mj_integratePos / mj_differentiatePos on caller-owned HOST vectors, float64, batched [batch, nq] / [batch, nv]
+// ---------------------------------------------------------------------------------------------------------------------
+int mjb_integrate_pos(const mjbModel* m, int batch, double* qpos, const double* qvel, double dt) {
+  if (!m || !qpos || !qvel || batch < 1) return fail(MJB_ERR_ARG, "bad argument");
+  const HostModel& h = m->h;
+  const auto& jt = h.I("jnt_type"); const auto& jq = h.I("jnt_qposadr"); const auto& jd = h.I("jnt_dofadr");
+  for (int e = 0; e < batch; e++) {
+    double* q = qpos + (size_t)e * h.nq; const double* v = qvel + (size_t)e * h.nv;
+    for (int j = 0; j < h.njnt; j++) {
+      const int qa = jq[j], da = jd[j];
+      if (jt[j] == JNT_FREE) {
+        for (int k = 0; k < 3; k++) q[qa + k] += dt * v[da + k];
+        double ax[3] = {v[da + 3], v[da + 4], v[da + 5]};
+        const double nrm = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        if (nrm < 1e-15) continue;
+        const double ang = dt * nrm, sn = std::sin(0.5 * ang) / nrm;
+        double qr[4] = {std::cos(0.5 * ang), ax[0] * sn, ax[1] * sn, ax[2] * sn}, out[4];
+        h_quat_mul(out, q + qa + 3, qr);
+        const double on = std::sqrt(out[0] * out[0] + out[1] * out[1] + out[2] * out[2] + out[3] * out[3]);
+        if (on < 1e-15) { q[qa + 3] = 1; q[qa + 4] = q[qa + 5] = q[qa + 6] = 0; }
+        else for (int k = 0; k < 4; k++) q[qa + 3 + k] = out[k] / on;
+      } else q[qa] += dt * v[da];
+    }
+  }
+  return MJB_OK;
+}
+
+int mjb_differentiate_pos(const mjbModel* m, int batch, double* qvel_out, double dt, const double* qpos1, const double* qpos2) {
+  if (!m || !qvel_out || !qpos1 || !qpos2 || batch < 1) return fail(MJB_ERR_ARG, "bad argument");
+  if (dt == 0) return fail(MJB_ERR_ARG, "dt must be non-zero");
+  const HostModel& h = m->h;
+  const auto& jt = h.I("jnt_type"); const auto& jq = h.I("jnt_qposadr"); const auto& jd = h.I("jnt_dofadr");
+  const double PI = 3.14159265358979323846;
+  for (int e = 0; e < batch; e++) {
+    const double *q1 = qpos1 + (size_t)e * h.nq, *q2 = qpos2 + (size_t)e * h.nq; double* v = qvel_out + (size_t)e * h.nv;
+    for (int j = 0; j < h.njnt; j++) {
+      const int qa = jq[j], da = jd[j];
+      if (jt[j] == JNT_FREE) {
+        for (int k = 0; k < 3; k++) v[da + k] = (q2[qa + k] - q1[qa + k]) / dt;
+        const double qn[4] = {q1[qa + 3], -q1[qa + 4], -q1[qa + 5], -q1[qa + 6]};
+        double qd[4];
+        h_quat_mul(qd, qn, q2 + qa + 3);
+        const double sn = std::sqrt(qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]);
+        if (sn < 1e-15) { v[da + 3] = v[da + 4] = v[da + 5] = 0; continue; }
+        double ang = 2 * std::atan2(sn, qd[0]);
+        if (ang > PI) ang -= 2 * PI;
+        const double k = ang / sn / dt;
+        v[da + 3] = qd[1] * k; v[da + 4] = qd[2] * k; v[da + 5] = qd[3] * k;
+      } else v[da] = (q2[qa] - q1[qa]) / dt;
+    }
+  }
+  return MJB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host mirror: ONE pinned float64 block per data object, one pack kernel + ONE copy per direction
+// ---------------------------------------------------------------------------------------------------------------------
+static int ensure_mirror(mjbData* d) {
+  if (d->mirror_host) return MJB_OK;
+  const HostModel& h = d->model->h;
+  const size_t B = (size_t)d->batch, n[6] = {(size_t)h.nq, (size_t)h.nv, (size_t)h.nu, (size_t)h.nv, (size_t)h.nv, 1};
+  size_t o = 0;
+  for (int k = 0; k < 6; k++) { d->mirror_off[k] = o; o += B * n[k]; }
+  d->mirror_off[6] = o;
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipHostMalloc((void**)&d->mirror_host, (o + 1) * sizeof(double), hipHostMallocDefault));   // + the engine-flags word
+  std::memset(d->mirror_host, 0, (o + 1) * sizeof(double));
+  if (dev_alloc(d, &d->mirror_dev, o + 1)) return fail(MJB_ERR_DEVICE, "device allocation of the mirror staging block failed");
+  return MJB_OK;
+}
+static const char* const kMirrorNames[6] = {"qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "time"};
+
+int mjb_host_view(mjbData* d, const char* name, double** host_ptr, long* per_env) {
+  if (!d || !name || !host_ptr) return fail(MJB_ERR_ARG, "NULL argument");
+  int rc = ensure_mirror(d);
+  if (rc != MJB_OK) return rc;
+  const HostModel& h = d->model->h;
+  const long n[6] = {h.nq, h.nv, h.nu, h.nv, h.nv, 1};
+  if (!std::strcmp(name, "engine_flags")) { *host_ptr = d->mirror_host + d->mirror_off[6]; if (per_env) *per_env = 0; return MJB_OK; }
+  for (int k = 0; k < 6; k++) if (!std::strcmp(name, kMirrorNames[k])) {
+    *host_ptr = d->mirror_host + d->mirror_off[k];
+    if (per_env) *per_env = n[k];
+    return MJB_OK;
+  }
+  return fail(MJB_ERR_ARG, std::string("no host mirror for array: ") + name);
+}
+
+static int mirror_pull(mjbData* d) {
+  const HostModel& h = d->model->h;
+  const long total = (long)d->mirror_off[6];
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (d->dtype == MJB_F32) hipLaunchKernelGGL(k_mirror_pack<float>, dim3(grid), dim3(256), 0, d->stream, d->df, h.nq, h.nv, h.nu, d->mirror_dev, total);
+  else hipLaunchKernelGGL(k_mirror_pack<double>, dim3(grid), dim3(256), 0, d->stream, d->dd, h.nq, h.nv, h.nu, d->mirror_dev, total);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(d->mirror_host, d->mirror_dev, (size_t)(total + 1) * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  return MJB_OK;
+}
+
+static int mirror_push(mjbData* d, int mask) {
+  mask &= 63;
+  if (!mask) return MJB_OK;
+  const HostModel& h = d->model->h;
+  int lo = 0, hi = 5;
+  while (!((mask >> lo) & 1)) lo++;
+  while (!((mask >> hi) & 1)) hi--;
+  const size_t a = d->mirror_off[lo], b = d->mirror_off[hi + 1];       // one contiguous span covering the edited fields
+  HIPCHK(hipMemcpyAsync(d->mirror_dev + a, d->mirror_host + a, (b - a) * sizeof(double), hipMemcpyHostToDevice, d->stream));
+  const long total = (long)d->mirror_off[6];
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (d->dtype == MJB_F32) hipLaunchKernelGGL(k_mirror_unpack<float>, dim3(grid), dim3(256), 0, d->stream, d->df, h.nq, h.nv, h.nu, (const double*)d->mirror_dev, total, mask);
+  else hipLaunchKernelGGL(k_mirror_unpack<double>, dim3(grid), dim3(256), 0, d->stream, d->dd, h.nq, h.nv, h.nu, (const double*)d->mirror_dev, total, mask);
+  HIPCHK(hipGetLastError());
+  return MJB_OK;
+}
+
+int mjb_sync_to_host(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  int rc = ensure_mirror(d);
+  if (rc != MJB_OK) return rc;
+  HIPCHK(hipSetDevice(d->device));
+  return mirror_pull(d);
+}
+
+int mjb_sync_to_device(mjbData* d, int field_mask) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  int rc = ensure_mirror(d);
+  if (rc != MJB_OK) return rc;
+  HIPCHK(hipSetDevice(d->device));
+  return mirror_push(d, field_mask);
+}
+
+int mjb_step_host(mjbData* d, int nstep, int field_mask) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (nstep < 0) return fail(MJB_ERR_ARG, "nstep must be >= 0");
+  int rc = ensure_mirror(d);
+  if (rc != MJB_OK) return rc;
+  HIPCHK(hipSetDevice(d->device));
+  if ((rc = mirror_push(d, field_mask)) != MJB_OK) return rc;
+  ObsSpecDev none; std::memset(&none, 0, sizeof(none));
+  if (nstep > 0 && (rc = launch(d, make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0), none, nullptr, false)) != MJB_OK) return rc;
+  if (nstep == 0 && (rc = launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, false)) != MJB_OK) return rc;   // mj_forward
+  return mirror_pull(d);
 }
 
 int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [24] per-phase cycle sums; zero unless built with -DMJB_PROFILE */) {

@@ -2424,6 +2424,10 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
     cn[CNT_CON_DROPPED] += c.con_dropped; cn[CNT_EFC_DROPPED] += c.efc_dropped;
     cn[CNT_BADQPOS] += badqpos; cn[CNT_BADQVEL] += badqvel; cn[CNT_BADQACC] += badqacc;
+#ifndef MJB_HOST_EMU
+    const int fl = (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0);
+    if (fl && d.flags) atomicOr(d.flags, fl);                  // rare: the host reads ONE word instead of the [batch, 8] counters
+#endif
   }
   if (a.write_kin) {
     for (int i = lane; i < 3 * m.nbody; i += G) {

@@ -109,6 +109,7 @@ struct DevData {
   TS *xpos, *xquat, *xipos, *site_xpos, *geom_xpos, *subtree_com, *sensordata;
   TS *qfrc_inverse, *actuator_moment;   // outputs of the inverse-dynamics mode: [batch, nv], [batch, nu, nv]
   int* counters;
+  int* flags;                 // one sticky word for the whole batch: bit 0 contacts dropped, 1 constraint rows dropped, 2 bad-state reset
   unsigned long long* prof;   // per-phase cycle sums (diagnostic -DMJB_PROFILE build only; null otherwise)
 };
 enum { PH_KIN = 0, PH_COM, PH_CRB, PH_COLL, PH_CONS, PH_VEL, PH_ACT, PH_SOLVE, PH_INTEG, PH_OTHER, PH_SOL_DIR, PH_SOL_LS, PH_CNT_LS = 12, PH_CNT_DIR, PH_CNT_FACT, PH_SOL_MV, PH_FAC_LOAD = 16, PH_FAC_PANEL, PH_FAC_BACK, PH_FAC_ALL, PH_N = 24 };

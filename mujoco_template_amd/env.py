@@ -67,6 +67,7 @@ class Env:
         self._substep = 0                 # physics steps since reset (decimation phase)
         self._device_steps = 0            # same count, as the step index of the device-side RNG stream
         self._warnings_reported = False
+        self._engine_warnings_reported = 0
         self._compat_warnings: list[str] = []
         self._select_actuator_groups(enabled_groups)
         if controller is not None:
@@ -218,6 +219,10 @@ class Env:
             self.data.sync_host()
         else:
             self._advance_on_host(n, info)
+        ew = getattr(self.data, "engine_warnings", None)
+        if ew and len(ew) > self._engine_warnings_reported:      # truncated physics (LDS caps) / bad-state resets, reported once each
+            info["engine_warnings"] = list(ew[self._engine_warnings_reported:])
+            self._engine_warnings_reported = len(ew)
         obs: Observation | None = self._ensure_extractor()(self.data) if return_obs else None
         # the user hooks run even without an observation (they then receive obs=None), like the reference
         reward = self.reward_fn(self.model, self.data, obs) if self.reward_fn else None

@@ -18,13 +18,12 @@ There is no CPU physics here: every ``mj_*`` call below launches HIP kernels.
 
 from __future__ import annotations
 
-import math
 from typing import Any
 
 import numpy as np
 
 from . import mjcf
-from ._capi import BatchSim, DeviceModel
+from ._capi import MIRROR_FIELDS, BatchSim, DeviceModel
 from .exceptions import ConfigError, LinearizationError
 from .mjcf import CompiledModel
 
@@ -119,6 +118,17 @@ class MjModel:
     def from_xml_string(cls, xml_text: str) -> "MjModel":
         return cls(mjcf.compile_xml_string(xml_text))
 
+    @classmethod
+    def from_binary_path(cls, mjb_path: str) -> "MjModel":
+        """Model saved by :meth:`save_binary` (C ABI ``mjb_model_load``; the flat table format of this engine, not MuJoCo's .mjb)."""
+        dm = DeviceModel.load(mjb_path)
+        model = cls(dm.compiled)
+        model._dm = dm
+        return model
+
+    def save_binary(self, mjb_path: str) -> None:
+        self._device_model().save(mjb_path)
+
     def _device_model(self) -> DeviceModel:
         if self._dm is None:
             self._dm = DeviceModel(self._c)
@@ -163,13 +173,16 @@ class MjData:
         self.batch = int(batch)
         self._sim = BatchSim(model._device_model(), self.batch, dtype=dtype, lanes=lanes, nconmax=nconmax, nefcmax=nefcmax,
                              device=device, env0=env0, specialize=specialize)
-        self._mirror: dict[str, np.ndarray] = {}
+        # state mirrors = numpy views over the library's pinned float64 block (mjb_host_view): ONE packed copy per direction
+        self._mirror: dict[str, np.ndarray] = {name: self._sim.host_view(name) for name in MIRROR_FIELDS}
+        self._flags = self._sim.host_view("engine_flags")          # one sticky word, refreshed by the same packed copy
         self._shadow: dict[str, np.ndarray] = {}
-        self._dev_newer: set[str] = set(_STATE) | set(_DERIVED) | {"time"}
-        self._time = np.zeros(self.batch)
+        self._state_stale = True                                   # the device state is newer than the mirror block
+        self._dev_newer: set[str] = set(_DERIVED)                  # derived arrays are pulled one by one, on demand
         self.act = np.zeros(0) if self.batch == 1 else np.zeros((self.batch, 0))
-        c = model._c
-        for name in _STATE + _DERIVED:
+        self.engine_warnings: list[str] = []
+        self._warned: set[str] = set()
+        for name in _DERIVED:
             _, n, _ = self._sim.array_ptr(name)
             if name == "actuator_moment":
                 shape = (self.batch, model.nu, model.nv)        # dense; MuJoCo's CSR triplet is derived in the properties below
@@ -178,43 +191,85 @@ class MjData:
             else:
                 shape = (self.batch, n)
             self._mirror[name] = np.zeros(shape)
-        self._views = {k: (v[0] if self.batch == 1 else v) for k, v in self._mirror.items()}
-        del c
+        self._views = {k: (v[0] if self.batch == 1 else v) for k, v in self._mirror.items() if k != "time"}
 
     # -- mirror protocol ---------------------------------------------------------
     @property
     def sim(self) -> BatchSim:
         return self._sim
 
+    def _refresh_shadow(self) -> None:
+        for name in MIRROR_FIELDS:
+            self._shadow[name] = self._mirror[name].copy()
+        self._state_stale = False
+
     def _pull(self, name: str) -> None:
-        if name in self._dev_newer:
-            if name == "time":
-                self._time[:] = self._sim.get("time")[:, 0]
-            else:
-                m = self._mirror[name]
-                m[...] = self._sim.get(name).reshape(m.shape)
-                if name in _STATE:
-                    self._shadow[name] = m.copy()
+        if name in MIRROR_FIELDS:
+            if self._state_stale:
+                self._sim.sync_to_host()
+                self._refresh_shadow()
+                self._check_engine_counters()
+        elif name in self._dev_newer:
+            m = self._mirror[name]
+            m[...] = self._sim.get(name).reshape(m.shape)
             self._dev_newer.discard(name)
 
+    def _edited_mask(self) -> int:
+        """Bit mask (order of ``MIRROR_FIELDS``) of the mirrors the user edited in place since they were last refreshed."""
+        if self._state_stale:
+            return 0                                               # nothing pulled since the last launch: nothing to compare against
+        mask = 0
+        for bit, name in enumerate(MIRROR_FIELDS):
+            if not np.array_equal(self._mirror[name], self._shadow[name]):
+                mask |= 1 << bit
+        return mask
+
     def push_host_edits(self) -> None:
-        """Upload mirrors the user edited in place since they were last pulled."""
-        for name in _STATE:
-            if name in self._dev_newer or name not in self._shadow:
-                continue
-            m = self._mirror[name]
-            if not np.array_equal(m, self._shadow[name]):
-                self._sim.set(name, m.reshape(self.batch, -1))
-                self._shadow[name] = m.copy()
+        """Upload mirrors the user edited in place since they were last pulled (one packed copy)."""
+        mask = self._edited_mask()
+        if mask:
+            self._sim.sync_to_device(mask)
+            for bit, name in enumerate(MIRROR_FIELDS):
+                if (mask >> bit) & 1:
+                    self._shadow[name] = self._mirror[name].copy()
+
+    def step_host(self, nstep: int) -> None:
+        """Host-driven step: edited fields up, ``nstep`` x mj_step (0 = mj_forward), whole state block back — one library call."""
+        self._sim.step_host(int(nstep), self._edited_mask())
+        self._refresh_shadow()
+        self._dev_newer = set(_DERIVED)
+        self._check_engine_counters()
 
     def mark_device_newer(self, eager: bool = False) -> None:
-        self._dev_newer = set(_STATE) | set(_DERIVED) | {"time"}
+        self._state_stale = True
+        self._dev_newer = set(_DERIVED)
         if eager:
             self.sync_host()
 
     def sync_host(self) -> None:
-        for name in _STATE + ("time",):
-            self._pull(name)
+        self._pull("qpos")
+
+    def _check_engine_counters(self) -> None:
+        """Surface truncated physics once: contacts / constraint rows beyond the LDS caps, bad-state auto-resets (the device
+        counters).  Cheap: one sticky flags word rides along with every mirror refresh; the [batch, 8] counters are
+        only fetched once it is non-zero."""
+        if int(self._flags[0]) == 0:
+            return
+        cn = self._sim.counters()
+        msgs = []
+        if int(cn["con_dropped"].sum()) or int(cn["efc_dropped"].sum()):
+            msgs.append(("dropped", f"{int(cn['con_dropped'].sum())} contact(s) / {int(cn['efc_dropped'].sum())} constraint row(s) beyond the per-environment "
+                         f"caps (nconmax={self._sim.nconmax}, nefcmax={self._sim.nefcmax}) were dropped: raise the caps at creation"))
+        nbad = int(cn["warn_badqpos"].sum() + cn["warn_badqvel"].sum() + cn["warn_badqacc"].sum())
+        if nbad:
+            msgs.append(("badstate", f"{nbad} bad-state auto-reset(s) (NaN / >1e10 in qpos, qvel or qacc): those environments restarted from qpos0"))
+        for key, text in msgs:
+            if key not in self._warned:
+                import warnings
+
+                self._warned.add(key)
+                self.engine_warnings.append(text)
+                warnings.warn(text, RuntimeWarning, stacklevel=3)
 
     def __getattr__(self, name: str) -> Any:
         views = self.__dict__.get("_views")
@@ -233,13 +288,13 @@ class MjData:
     @property
     def time(self):
         self._pull("time")
-        return float(self._time[0]) if self.batch == 1 else self._time
+        t = self._mirror["time"]
+        return float(t[0, 0]) if self.batch == 1 else t[:, 0]
 
     @time.setter
     def time(self, value) -> None:
         self._pull("time")
-        self._time[...] = value
-        self._sim.set("time", self._time.reshape(self.batch, 1))
+        self._mirror["time"][:, 0] = value
 
     # data.actuator_moment is CSR in MuJoCo >= 3.1 (moment_rownnz / moment_rowadr / moment_colind); the reference densifies it
     # with mju_sparse2dense (mujoco_template/setpoints.py:40-47).  The engine keeps it dense [nu, nv]; these views present
@@ -276,11 +331,11 @@ def _names(model: MjModel) -> CompiledModel:
 
 
 def mj_name2id(model: MjModel, objtype: int, name: str) -> int:
-    return int(_names(model).name2id(int(objtype), name))
+    return model._device_model().name2id(int(objtype), name)               # C ABI: mjb_model_name2id
 
 
 def mj_id2name(model: MjModel, objtype: int, idx: int) -> str | None:
-    return _names(model).id2name(int(objtype), int(idx))
+    return model._device_model().id2name(int(objtype), int(idx))           # C ABI: mjb_model_id2name
 
 
 def _check(model: MjModel, data: MjData) -> None:
@@ -290,9 +345,7 @@ def _check(model: MjModel, data: MjData) -> None:
 
 def mj_forward(model: MjModel, data: MjData) -> None:
     _check(model, data)
-    data.push_host_edits()
-    data._sim.forward()
-    data.mark_device_newer(eager=True)
+    data.step_host(0)
 
 
 def mj_inverse(model: MjModel, data: MjData) -> None:
@@ -316,9 +369,16 @@ def mju_sparse2dense(res: np.ndarray, mat: np.ndarray, rownnz: np.ndarray, rowad
 
 def mj_step(model: MjModel, data: MjData, nstep: int = 1) -> None:
     _check(model, data)
-    data.push_host_edits()
-    data._sim.step(int(nstep))
-    data.mark_device_newer(eager=True)
+    if int(nstep) < 1:
+        raise ConfigError("mj_step: nstep must be >= 1")
+    data.step_host(int(nstep))
+
+
+def mj_saveModel(model: MjModel, filename: str, buffer=None) -> None:
+    """``mujoco.mj_saveModel(m, filename, buffer)`` (reference model.py:49): the compiled table through ``mjb_model_save``."""
+    if buffer is not None:
+        raise ConfigError("mj_saveModel: saving into a caller buffer is not supported; pass a file name")
+    model.save_binary(filename)
 
 
 def mj_resetData(model: MjModel, data: MjData) -> None:
@@ -377,57 +437,19 @@ def mj_jacSubtreeCom(model, data, jacp, body_id) -> None:
     _jac(model, data, 3, body_id, jacp, None)
 
 
-# position manifold helpers run on the host: they act on caller-owned numpy vectors
-# (controllers call them every step, reference examples/humanoid/controllers/lqr.py:153)
-
-def _quat_mul(a, b):
-    return np.array([
-        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
-        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
-        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
-        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0],
-    ])
-
+# position manifold helpers: C ABI (mjb_integrate_pos / mjb_differentiate_pos), in place on caller-owned float64 vectors,
+# [n] or [batch, n] (controllers call them every step, reference examples/humanoid/controllers/lqr.py:153)
 
 def mj_integratePos(model: MjModel, qpos: np.ndarray, qvel: np.ndarray, dt: float) -> None:
-    c = model._c
-    for j in range(c.njnt):
-        qa, da = int(c.jnt_qposadr[j]), int(c.jnt_dofadr[j])
-        if c.jnt_type[j] == mjcf.JNT_FREE:
-            qpos[qa:qa + 3] += dt * qvel[da:da + 3]
-            w = np.asarray(qvel[da + 3:da + 6], dtype=float)
-            n = float(np.linalg.norm(w))
-            if n > 1e-15:
-                ang = dt * n
-                qr = np.concatenate([[math.cos(ang / 2)], w / n * math.sin(ang / 2)])
-                q = _quat_mul(qpos[qa + 3:qa + 7], qr)
-                qpos[qa + 3:qa + 7] = q / np.linalg.norm(q)
-        else:
-            qpos[qa] += dt * qvel[da]
+    model._device_model().integrate_pos(qpos, qvel, float(dt))
 
 
 def mj_differentiatePos(model: MjModel, qvel: np.ndarray, dt: float, qpos1: np.ndarray, qpos2: np.ndarray) -> None:
-    c = model._c
-    for j in range(c.njnt):
-        qa, da = int(c.jnt_qposadr[j]), int(c.jnt_dofadr[j])
-        if c.jnt_type[j] == mjcf.JNT_FREE:
-            qvel[da:da + 3] = (qpos2[qa:qa + 3] - qpos1[qa:qa + 3]) / dt
-            q1 = np.asarray(qpos1[qa + 3:qa + 7], dtype=float)
-            qd = _quat_mul(np.array([q1[0], -q1[1], -q1[2], -q1[3]]), np.asarray(qpos2[qa + 3:qa + 7], dtype=float))
-            s = float(np.linalg.norm(qd[1:]))
-            if s < 1e-15:
-                qvel[da + 3:da + 6] = 0.0
-            else:
-                ang = 2 * math.atan2(s, qd[0])
-                if ang > math.pi:
-                    ang -= 2 * math.pi
-                qvel[da + 3:da + 6] = qd[1:] / s * ang / dt
-        else:
-            qvel[da] = (qpos2[qa] - qpos1[qa]) / dt
+    model._device_model().differentiate_pos(qvel, float(dt), qpos1, qpos2)
 
 
 __all__ = [
     "MjModel", "MjData", "mjtObj", "mjtJoint", "FatalError", "mj_name2id", "mj_id2name", "mj_forward", "mj_step",
-    "mj_inverse", "mju_sparse2dense", "mj_resetData", "mj_resetDataKeyframe", "mj_subtreeCoM", "mjd_transitionFD", "mj_jacSite", "mj_jacBody",
+    "mj_inverse", "mju_sparse2dense", "mj_saveModel", "mj_resetData", "mj_resetDataKeyframe", "mj_subtreeCoM", "mjd_transitionFD", "mj_jacSite", "mj_jacBody",
     "mj_jacBodyCom", "mj_jacSubtreeCom", "mj_integratePos", "mj_differentiatePos",
 ]

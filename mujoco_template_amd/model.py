@@ -5,8 +5,8 @@ Public surface = the reference's (``mujoco_template/model.py:11-105``): construc
 ``reset`` / ``reset_keyframe``, actuator-group enabling through ``opt.disableactuator``.  Differences that come with
 the engine: the constructors forward keyword-only creation arguments (``batch``, ``dtype``, ``device``, ``lanes``,
 ``nconmax``, ``nefcmax``, ``env0``, ``specialize``) to ``MjData``; every physics call is ONE C-ABI call for the whole batch;
-there is no binary model format, so ``from_binary_path`` / ``save_binary`` refuse with ``ConfigError`` the way the reference
-does on a MuJoCo build that lacks them.
+``from_binary_path`` / ``save_binary`` use the engine's own flat model table (``mjb_model_save`` / ``mjb_model_load``), so a host
+without the Python MJCF compiler can load a model compiled once.
 """
 
 from __future__ import annotations
@@ -43,11 +43,15 @@ class ModelHandle:
         return cls(model, data=data)
 
     @classmethod
-    def from_binary_path(cls, mjb_path: str) -> "ModelHandle":
-        raise ConfigError("This build has no from_binary_path(): compile from XML instead.")
+    def from_binary_path(cls, mjb_path: str, **data_kwargs) -> "ModelHandle":
+        """A model written by :meth:`save_binary` (C ABI ``mjb_model_load``): this engine's own flat table format, not MuJoCo's .mjb."""
+        return cls(mj.MjModel.from_binary_path(mjb_path), **data_kwargs)
 
     def save_binary(self, mjb_path: str) -> None:
-        raise ConfigError("This build has no mj_saveModel().")
+        try:
+            mj.mj_saveModel(self.model, mjb_path, None)
+        except Exception as exc:
+            raise ConfigError(f"Could not save model to {mjb_path}: {exc}") from exc
 
     # -- what was built -----------------------------------------------------------------------------
     @property

@@ -409,3 +409,69 @@ def test_state_control_recorder_hook_and_bulk_feeds(tmp_path):
     bad = StateControlRecorder(env, probes=[DataProbe("vec", lambda e, r: np.zeros(2))])
     with pytest.raises(mt.ConfigError):
         bad(env.step())
+
+
+def test_host_mirror_is_one_pinned_block_and_steps_match_the_device_path():
+    """mjb_host_view / mjb_step_host (VERDICT r1 "finish the boundary"): data.qpos & co are numpy views over the library's pinned
+    float64 block (stable objects, obs copy=False aliases them), in-place edits travel as one packed upload, and the
+    host-driven step gives exactly the state the plain device path (mjb_set_array + mjb_step) gives."""
+    from mujoco_template_amd._capi import BatchSim
+
+    B = 6
+    h = mt.ModelHandle.from_xml_path(MODELS["humanoid"], batch=B, dtype="float32")
+    d = h.data
+    q_view, v_view, u_view = d.qpos, d.qvel, d.ctrl
+    assert q_view is d.qpos and np.shares_memory(q_view, d.sim.host_view("qpos"))        # the same pinned memory every time
+    span = [d.sim.host_view(n) for n in ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "time")]
+    for a, b in zip(span[:-1], span[1:]):                                                  # contiguous fields of ONE block
+        assert a.ctypes.data + a.nbytes == b.ctypes.data
+    rng = np.random.default_rng(0)
+    ref = BatchSim(h.model._device_model(), B, dtype="float32")
+    for s in range(5):
+        u = rng.uniform(-1, 1, size=(B, h.model.nu))
+        d.ctrl[:] = u                                                                      # in-place edit, as reference controllers do
+        if s == 2:
+            d.qvel[:, 0] += 0.25
+            ref.set("qvel", d.qvel)
+        ref.set("ctrl", u)
+        h.step()
+        ref.step(1)
+        assert d.qpos is q_view and d.qvel is v_view and d.ctrl is u_view
+        assert np.array_equal(d.qpos, ref.get("qpos")) and np.array_equal(d.qvel, ref.get("qvel"))
+        assert np.array_equal(d.qacc_warmstart, ref.get("qacc_warmstart"))
+        assert d.time == pytest.approx((s + 1) * h.model.opt.timestep)
+    d.time = 0.5
+    h.step()
+    assert d.time == pytest.approx(0.5 + h.model.opt.timestep)
+    assert d.sim.get("time")[:, 0] == pytest.approx(0.5 + h.model.opt.timestep)
+    assert d.engine_warnings == []
+
+
+def test_truncated_physics_is_surfaced_once():
+    """contacts / rows beyond the LDS caps are dropped AND reported: one RuntimeWarning, data.engine_warnings,
+    info['engine_warnings'] of the first Env.step after it was seen."""
+    with pytest.warns(RuntimeWarning, match="beyond the per-environment caps"):
+        env = mt.Env.from_xml_path(MODELS["humanoid"], batch=4, dtype="float32", nconmax=1, nefcmax=8, controller=None)
+        infos = [env.step(return_obs=False).info for _ in range(12)]                       # the standing humanoid has 4+ foot contacts
+    seen = [i for i in infos if "engine_warnings" in i]
+    assert len(seen) == 1 and "nconmax=1" in seen[0]["engine_warnings"][0]               # reported once
+    assert env.data.counters()["con_dropped"].sum() > 0 and len(env.data.engine_warnings) == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert "engine_warnings" not in env.step(return_obs=False).info
+        full = mt.Env.from_xml_path(MODELS["humanoid"], batch=4, dtype="float32")
+        for _ in range(30):
+            assert "engine_warnings" not in full.step(return_obs=False).info
+        assert full.data.engine_warnings == []
+
+
+def test_binary_model_steps_like_the_xml_model(tmp_path):
+    a = mt.ModelHandle.from_xml_path(MODELS["drone2"], batch=3, dtype="float64")
+    path = str(tmp_path / "m.mjbm")
+    a.save_binary(path)
+    b = mt.ModelHandle.from_binary_path(path, batch=3, dtype="float64")
+    for h in (a, b):
+        h.reset_keyframe("hover")
+        h.data.ctrl[:] = 4.0
+        h.step(20)
+    assert np.array_equal(a.data.qpos, b.data.qpos) and np.array_equal(a.data.qvel, b.data.qvel)

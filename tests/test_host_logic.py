@@ -192,3 +192,61 @@ def test_bench_wrong_world_size_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_batched_manifold_helpers_through_the_c_abi_match_oracle(oracle):
+    """mjb_integrate_pos / mjb_differentiate_pos: float64, [batch, nq] <-> [batch, nv], against the oracle's
+    mjo_integrate_pos / mjo_differentiate_pos (reference call sites linearization.py:12,67,77; lqr.py:153)."""
+    m, d = oracle("humanoid")
+    model = mj.MjModel(m.compiled)
+    rng = np.random.default_rng(5)
+    B = 7
+    q1 = np.stack([d.integrate_pos(m.compiled.qpos0, rng.normal(size=model.nv) * 0.5, 1.0) for _ in range(B)])
+    v = rng.normal(size=(B, model.nv)) * 2.0
+    q2 = q1.copy()
+    mj.mj_integratePos(model, q2, v, 0.21)
+    ref = np.stack([d.integrate_pos(q1[e], v[e], 0.21) for e in range(B)])
+    assert np.abs(q2 - ref).max() < 1e-14
+    dv = np.zeros((B, model.nv))
+    mj.mj_differentiatePos(model, dv, 0.21, q1, q2)
+    refd = np.stack([d.differentiate_pos(q1[e], q2[e], 0.21) for e in range(B)])
+    assert np.abs(dv - refd).max() < 1e-13 and np.abs(dv - v).max() < 1e-12
+    # a rotation beyond pi comes back as the shorter way round (MuJoCo's mju_subQuat convention)
+    big = np.zeros(model.nv); big[3] = 4.0
+    qa = np.array(m.compiled.qpos0); qb = qa.copy()
+    mj.mj_integratePos(model, qb, big, 1.0)
+    back = np.zeros(model.nv)
+    mj.mj_differentiatePos(model, back, 1.0, qa, qb)
+    assert back[3] == pytest.approx(4.0 - 2 * np.pi, abs=1e-12)
+    with pytest.raises(mt.ConfigError):
+        mj.mj_integratePos(model, q2.astype(np.float32), v, 0.1)           # in place on float64 only
+    with pytest.raises(mt.ConfigError):
+        mj.mj_integratePos(model, np.zeros(model.nq + 1), v[0], 0.1)
+
+
+def test_binary_model_round_trip_and_names_through_the_c_abi(tmp_path):
+    """mjb_model_save / mjb_model_load / mjb_model_field_at / mjb_model_name2id: ModelHandle.from_binary_path + save_binary
+    (reference model.py:28-31, :45-51) on the engine's own flat table; a host without the Python compiler can load it."""
+    model = mj.MjModel.from_xml_path(os.path.join(ROOT, "models", "drone2", "scene.xml"))
+    path = str(tmp_path / "drone.mjbm")
+    mj.mj_saveModel(model, path, None)
+    again = mj.MjModel.from_binary_path(path)
+    a, b = model.compiled, again.compiled
+    assert (a.nq, a.nv, a.nu, a.nbody, a.npair, a.timestep, a.name) == (b.nq, b.nv, b.nu, b.nbody, b.npair, b.timestep, b.name)
+    assert set(a.arrays) == set(b.arrays)
+    for k in a.arrays:
+        assert np.asarray(a.arrays[k]).shape == np.asarray(b.arrays[k]).shape, k
+        assert np.array_equal(np.asarray(a.arrays[k], dtype=float), np.asarray(b.arrays[k], dtype=float)), k
+    assert a.names == b.names
+    for obj, name in ((mj.mjtObj.mjOBJ_SITE, "imu"), (mj.mjtObj.mjOBJ_BODY, "x2"), (mj.mjtObj.mjOBJ_KEY, "hover"), (mj.mjtObj.mjOBJ_ACTUATOR, "thrust1")):
+        assert mj.mj_name2id(again, obj, name) == mj.mj_name2id(model, obj, name) >= 0
+        assert mj.mj_id2name(again, obj, mj.mj_name2id(again, obj, name)) == name
+    assert mj.mj_name2id(again, mj.mjtObj.mjOBJ_XBODY, "x2") == mj.mj_name2id(again, mj.mjtObj.mjOBJ_BODY, "x2")
+    assert mj.mj_id2name(again, mj.mjtObj.mjOBJ_BODY, 10**6) is None
+    bad = tmp_path / "bad.mjbm"
+    bad.write_bytes(open(path, "rb").read()[:1000])
+    with pytest.raises(ValueError, match="truncated|corrupt"):
+        mj.MjModel.from_binary_path(str(bad))
+    bad.write_bytes(b"not a model")
+    with pytest.raises(ValueError, match="magic"):
+        mj.MjModel.from_binary_path(str(bad))
