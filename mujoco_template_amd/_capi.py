@@ -161,63 +161,104 @@ def _source_from(fn, *args) -> str:
     return buf.value.decode()
 
 
+def spec_scheduler(source: str) -> str | None:
+    """The machine scheduler the specialised kernel is compiled with — a stated rule, not a retry: the iterative ILP strategy
+    for one-wave-per-environment kernels (``MJB_SPEC_G == 64``: +4 % on the humanoid, the only place it was measured to pay),
+    LLVM's default for the packed kernels (G = 8 / 16).  With the iterative strategy ROCm 7.2.0's clang crashes in the greedy
+    register allocator on the specialised G = 8 kernel of the tests' BASE_XML model (``profiles/r02_hipcc_iterative_ilp_crash.txt``)."""
+    import re
+
+    m = re.search(r"#define MJB_SPEC_G (\d+)", source)
+    return "iterative-ilp" if m and int(m.group(1)) == 64 else None
+
+
+def _private_cache_dir() -> str:
+    """Per-user cache for read-only installs: created 0700, must be a real directory owned by this user with no group / other
+    write bit (another local user must not be able to plant a code object that ``hipModuleLoadData`` would then run)."""
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    path = os.path.join(base, "mujoco_template_amd", "jit")
+    try:
+        os.makedirs(path, mode=0o700, exist_ok=True)
+        st = os.lstat(path)
+    except OSError as exc:
+        raise TemplateError(f"no writable cache directory for the specialised kernel: {exc}") from exc
+    import stat
+
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise TemplateError(f"refusing the kernel cache {path}: it must be a directory owned by uid {os.getuid()} without group/other write access")
+    return path
+
+
+def _read_private(path: str) -> bytes:
+    """Read a cached code object without following a symlink at the final component.  Objects in the in-tree cache carry the
+    trust of the package itself (they ship beside ``libmjbatch.so``); anything else must be owned by this user and not writable
+    by others."""
+    fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    try:
+        st = os.fstat(fd)
+        in_tree = os.path.dirname(os.path.abspath(path)) == os.path.abspath(_JIT_DIR)
+        if not in_tree and (st.st_uid != os.getuid() or (st.st_mode & 0o022)):
+            raise TemplateError(f"refusing the cached kernel {path}: not owned by uid {os.getuid()} or writable by others")
+        with os.fdopen(fd, "rb", closefd=False) as fh:
+            return fh.read()
+    finally:
+        os.close(fd)
+
+
 def compile_spec(source: str, *, force: bool = False) -> str:
     """Compile a specialised translation unit (``mjb_*spec_source``) to a gfx950 code object; returns its path.
 
-    Cached in-tree (``mujoco_template_amd/_jit/``, keyed by the source text and the kernel headers), so the objects built
-    by ``__graft_entry__.build()`` on a GPU-less machine travel with the tree.  hipcc cross-compiles without a GPU.
+    Cached in-tree (``mujoco_template_amd/_jit/``, keyed by the source text, the kernel headers and the scheduler rule), so
+    the objects built by ``__graft_entry__.build()`` on a GPU-less machine travel with the tree; a read-only install uses a
+    private per-user cache (0700, ownership checked).  hipcc cross-compiles without a GPU.
     """
     import hashlib
     import shutil
     import subprocess
 
     extra = os.environ.get("MJB_SPEC_FLAGS", "").split()        # experiments, e.g. -DMJB_WPS=3 (register budget for 3 waves/SIMD)
-    h = hashlib.sha1((source + " ".join(extra) + " sched=iterative-ilp").encode())
+    sched = spec_scheduler(source)
+    h = hashlib.sha1((source + " ".join(extra) + f" sched={sched}").encode())
     for f in ("mjb_types.hpp", "mjb_device.hpp", "mjb_kernels.hpp"):
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(fh.read())
     key = h.hexdigest()[:20]
-    out = os.path.join(_JIT_DIR, f"k_step_spec_{key}.hsaco")
-    if os.path.exists(out) and not force:
-        return out
     jit_dir = _JIT_DIR
     try:
         os.makedirs(jit_dir, exist_ok=True)
         if not os.access(jit_dir, os.W_OK):
             raise OSError("not writable")
-    except OSError:                                            # read-only install: per-user cache under the temp directory
-        import tempfile
-
-        jit_dir = os.path.join(tempfile.gettempdir(), f"mjb_jit_{os.getuid()}")
-        try:
-            os.makedirs(jit_dir, exist_ok=True)
-        except OSError as exc:
-            raise TemplateError(f"no writable cache directory for the specialised kernel: {exc}") from exc
-        out = os.path.join(jit_dir, f"k_step_spec_{key}.hsaco")
-        if os.path.exists(out) and not force:
-            return out
+    except OSError:                                            # read-only install
+        jit_dir = _private_cache_dir()
+    out = os.path.join(jit_dir, f"k_step_spec_{key}.hsaco")
+    if os.path.exists(out) and not force:
+        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise TemplateError("hipcc not found: cannot specialise the step kernel (the generic kernel remains available)")
     src = os.path.join(jit_dir, f"k_step_spec_{key}.hip")
+    tmp = out + f".tmp{os.getpid()}"
     try:
-        with open(src, "w") as fh:
+        fd = os.open(src, os.O_WRONLY | os.O_CREAT | os.O_TRUNC | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "w") as fh:
             fh.write(source)
     except OSError as exc:
         raise TemplateError(f"cannot write the specialised kernel source: {exc}") from exc
-    tmp = out + f".tmp{os.getpid()}"
     base = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on"]
     tail = [*extra, "-I", _CSRC, "-o", tmp, src]
-    # the iterative ILP scheduler is worth ~4 % on the humanoid but has been seen to crash the compiler on tiny models:
-    # try it first, fall back to the default scheduler (same arithmetic either way)
-    attempts = ([*base, "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", *tail], [*base, *tail])
+    attempts = [[*base, "-mllvm", f"-amdgpu-sched-strategy={sched}", *tail], [*base, *tail]] if sched else [[*base, *tail]]
     err = ""
-    for cmd in attempts:
+    for k, cmd in enumerate(attempts):
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         except (OSError, subprocess.SubprocessError) as exc:
             raise TemplateError(f"hipcc could not be run: {exc}") from exc
         if r.returncode == 0 and os.path.exists(tmp):
+            if k > 0:                                          # the rule's scheduler failed: say so, with the evidence
+                import warnings
+
+                warnings.warn(f"hipcc failed with -amdgpu-sched-strategy={sched} on this specialised kernel; compiled with the default "
+                              f"scheduler instead (same arithmetic).  stderr tail:\n{err[-1200:]}", RuntimeWarning, stacklevel=2)
             break
         err = r.stderr
         if os.path.exists(tmp):
@@ -384,8 +425,7 @@ class BatchSim:
         use it for every later launch on this object.  float32 only; identical arithmetic to the generic kernel."""
         if self.dtype != "float32":
             raise ConfigError("only the float32 step kernel is specialised")
-        with open(compile_spec(self.spec_source()), "rb") as fh:
-            image = fh.read()
+        image = _read_private(compile_spec(self.spec_source()))
         _check(load_library().mjb_spec_load(self.ptr, image, len(image)))
         self.specialized = True
 

@@ -1394,24 +1394,36 @@ template <typename T, int G> MJB_DEV void collide_pass(Ctx<T>& c, int p, bool va
         T pt[3] = {p2[0] + z2[0] * x, p2[1] + z2[1] * x, p2[2] + z2[2] * x};
         n = nc_sphere_sphere(p1, s1[0], pt, s2[0], margin, rc[0]);
       } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {
+        // mjraw_CapsuleCapsule: nearest points of the axis segments -> sphere-sphere; PARALLEL axes: the four end caps in the order
+        // (+1, -1 of capsule 1, +1, -1 of capsule 2), every end that projects inside the other segment gives a contact, at most two.
+        // "Parallel" is |det| < mjMINVAL in float64; fp32 cannot resolve det below ~1e-7 ma mc, so the fp32 kernel takes the
+        // parallel branch for |det| < 1e-6 ma mc (axes within 1e-3 rad), where the general formula would divide noise by noise.
         T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
         T ma = dot3(z1, z1), mb = -dot3(z1, z2), mc = dot3(z2, z2), u = -dot3(z1, dif), v = dot3(z2, dif);
         T det = ma * mc - mb * mb, x1, x2;
-        if (t_abs(det) >= (T)1e-12) {
+        if (t_abs(det) >= (sizeof(T) == 4 ? (T)1e-6 * ma * mc : Num<T>::minval())) {
           x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det;
           if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; }
           else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb * s1[1]) / mc; }
           if (x2 > s2[1]) { x2 = s2[1]; x1 = t_min(t_max((u - mb * s2[1]) / ma, -s1[1]), s1[1]); }
           else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = t_min(t_max((u + mb * s2[1]) / ma, -s1[1]), s1[1]); }
+          T v1[3] = {p1[0] + z1[0] * x1, p1[1] + z1[1] * x1, p1[2] + z1[2] * x1};
+          T v2[3] = {p2[0] + z2[0] * x2, p2[1] + z2[1] * x2, p2[2] + z2[2] * x2};
+          n = nc_sphere_sphere(v1, s1[0], v2, s2[0], margin, rc[0]);
         } else {
-          T lo = -s1[1], hi = s1[1], c2 = -dot3(z1, dif), sgn = mb < 0 ? (T)1 : (T)-1;
-          lo = t_max(lo, c2 - s2[1]); hi = t_min(hi, c2 + s2[1]);
-          x1 = lo <= hi ? (T)0.5 * (lo + hi) : (c2 > 0 ? s1[1] : -s1[1]);
-          x2 = t_min(t_max(sgn * (x1 - c2), -s2[1]), s2[1]);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (n >= 2) continue;
+            bool ok;
+            if (k < 2) { x1 = k == 0 ? s1[1] : -s1[1]; x2 = (v - mb * x1) / mc; ok = x2 >= -s2[1] && x2 <= s2[1]; }
+            else { x2 = k == 2 ? s2[1] : -s2[1]; x1 = (u - mb * x2) / ma; ok = x1 >= -s1[1] && x1 <= s1[1]; }
+            if (!ok) continue;
+            T v1[3] = {p1[0] + z1[0] * x1, p1[1] + z1[1] * x1, p1[2] + z1[2] * x1};
+            T v2[3] = {p2[0] + z2[0] * x2, p2[1] + z2[1] * x2, p2[2] + z2[2] * x2};
+            RawCon<T> tmp;
+            if (nc_sphere_sphere(v1, s1[0], v2, s2[0], margin, tmp)) { if (n == 0) rc[0] = tmp; else rc[1] = tmp; n++; }
+          }
         }
-        T v1[3] = {p1[0] + z1[0] * x1, p1[1] + z1[1] * x1, p1[2] + z1[2] * x1};
-        T v2[3] = {p2[0] + z2[0] * x2, p2[1] + z2[1] * x2, p2[2] + z2[2] * x2};
-        n = nc_sphere_sphere(v1, s1[0], v2, s2[0], margin, rc[0]);
       }
     }
     int total, off = gscan_small<G>(n, lane, total);

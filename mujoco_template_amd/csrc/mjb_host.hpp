@@ -197,7 +197,7 @@ struct HostModel {
     int nc = 0;
     for (int p = 0; p < npair; p++) {
       int t1 = gt[g1[p]], t2 = gt[g2[p]];
-      nc += (t1 == G_PLANE && t2 == G_CAPSULE) ? 2 : (t1 == G_PLANE && t2 == G_BOX) ? 4 : 1;
+      nc += ((t1 == G_PLANE && t2 == G_CAPSULE) || (t1 == G_CAPSULE && t2 == G_CAPSULE)) ? 2 : (t1 == G_PLANE && t2 == G_BOX) ? 4 : 1;
     }
     ncon_alloc = nc;
     nefc_alloc = 2 * njnt + 2 * ntendon + 4 * nc;

@@ -3,8 +3,8 @@
 
 ``use_native=True`` runs the batched ``mjd_transitionFD`` on the GPU in float64: every
 perturbed replica (2(2nv+nu)+1 per environment) is one lane-group of one launch.
-``use_native=False`` reproduces the reference's Python fallback loop shape (``horizon_steps``)
-on top of the engine.  Note: the reference fallback's ``_dqpos`` passes (after, base) to
+``use_native=False`` is the reference's Python fallback
+(centred differences over ``horizon_steps`` steps) — batched and in float64 on a temporary twin of the data.  Note: the reference fallback's ``_dqpos`` passes (after, base) to
 ``mj_differentiatePos`` which yields ``(base - after)``, i.e. sign-flipped position rows versus
 the native path; this implementation uses the native convention for both.
 """
@@ -17,7 +17,6 @@ import numpy as np
 
 from . import mj
 from .exceptions import LinearizationError
-from .state_utils import _restore_state, _snapshot_state
 
 
 def _native_transition_fd(model: Any, data: Any, eps: float = 1e-6, centered: bool = True) -> tuple[np.ndarray, np.ndarray]:
@@ -33,53 +32,61 @@ def _native_transition_fd(model: Any, data: Any, eps: float = 1e-6, centered: bo
 
 
 def _fd_linearization(model: Any, data: Any, eps: float = 1e-6, horizon_steps: int = 1) -> tuple[np.ndarray, np.ndarray]:
-    if data.batch != 1:
-        raise LinearizationError("the Python FD fallback supports batch=1; use use_native=True for batches")
-    nv, nu = model.nv, model.nu
-    nx = 2 * nv
-    snap = _snapshot_state(data)
-    base_q, base_v, base_u = np.array(data.qpos), np.array(data.qvel), np.array(data.ctrl)
-
-    def rollout() -> np.ndarray:
-        mj.mj_step(model, data, horizon_steps)
-        dq = np.zeros(nv)
-        mj.mj_differentiatePos(model, dq, 1.0, base_q, np.array(data.qpos))
-        return np.concatenate([dq, np.array(data.qvel) - base_v])
-
-    def perturbed(kind: str, idx: int, sign: float) -> np.ndarray:
-        _restore_state(data, snap)
-        if kind == "q":
-            q = base_q.copy()
-            e = np.zeros(nv)
-            e[idx] = sign * eps
-            mj.mj_integratePos(model, q, e, 1.0)
-            data.qpos[...] = q
-        elif kind == "v":
-            data.qvel[idx] += sign * eps
-        else:
-            data.ctrl[idx] = base_u[idx] + sign * eps
-        return rollout()
-
-    try:
-        A = np.zeros((nx, nx))
-        Bm = np.zeros((nx, nu))
-        for i in range(nv):
-            A[:, i] = (perturbed("q", i, 1.0) - perturbed("q", i, -1.0)) / (2.0 * eps)
-            A[:, nv + i] = (perturbed("v", i, 1.0) - perturbed("v", i, -1.0)) / (2.0 * eps)
-        for i in range(nu):
-            Bm[:, i] = (perturbed("u", i, 1.0) - perturbed("u", i, -1.0)) / (2.0 * eps)
-        return A, Bm
-    finally:
-        _restore_state(data, snap)
-        mj.mj_forward(model, data)
+    """The reference's Python fallback (``linearization.py:38-120``: centred differences over ``horizon_steps`` steps, every input
+    nudged by +-eps), batched: all ``2 (2 nv + nu)`` perturbed replicas of all environments advance together in ONE fused
+    launch of a temporary FLOAT64 twin of ``data`` (eps = 1e-6 differences are meaningless in fp32: ADVICE r1), the tangent-space
+    differences are formed by the batched ``mjb_integrate_pos`` / ``mjb_differentiate_pos``.  ``data`` itself is not touched.
+    Position rows use the native sign convention."""
+    if horizon_steps < 1:
+        raise LinearizationError("horizon_steps must be >= 1")
+    if not eps > 0:
+        raise LinearizationError("eps must be > 0")
+    nq, nv, nu, B = model.nq, model.nv, model.nu, data.batch
+    nin, nx = 2 * nv + nu, 2 * nv
+    ncol = 2 * nin
+    data.push_host_edits()
+    data.sync_host()
+    two = lambda x: np.asarray(x, dtype=np.float64).reshape(B, -1)          # noqa: E731
+    q, v, u, ws = two(data.qpos), two(data.qvel), two(data.ctrl), two(data.qacc_warmstart)
+    t = np.broadcast_to(np.asarray(data.time, dtype=np.float64).reshape(-1), (B,))
+    Q = np.repeat(q[:, None, :], ncol, axis=1)
+    V = np.repeat(v[:, None, :], ncol, axis=1)
+    U = np.repeat(u[:, None, :], ncol, axis=1)
+    dq = np.zeros((B, ncol, nv))
+    for k in range(nv):
+        dq[:, 2 * k, k], dq[:, 2 * k + 1, k] = eps, -eps
+        V[:, 2 * (nv + k), k] += eps
+        V[:, 2 * (nv + k) + 1, k] -= eps
+    for k in range(nu):
+        U[:, 2 * (2 * nv + k), k] += eps
+        U[:, 2 * (2 * nv + k) + 1, k] -= eps
+    Qf = np.ascontiguousarray(Q.reshape(B * ncol, nq))
+    mj.mj_integratePos(model, Qf, np.ascontiguousarray(dq.reshape(B * ncol, nv)), 1.0)
+    twin = data.float64_twin(B * ncol)
+    twin.set("qpos", Qf)
+    twin.set("qvel", V.reshape(B * ncol, nv))
+    twin.set("ctrl", U.reshape(B * ncol, nu))
+    twin.set("qacc_warmstart", np.repeat(ws[:, None, :], ncol, axis=1).reshape(B * ncol, nv))
+    twin.set("time", np.repeat(t[:, None], ncol, axis=1).reshape(B * ncol, 1))
+    twin.step(int(horizon_steps))
+    Qn, Vn = twin.get("qpos"), twin.get("qvel")
+    dQ = np.zeros((B * ncol, nv))
+    mj.mj_differentiatePos(model, dQ, 1.0, np.ascontiguousarray(np.repeat(q[:, None, :], ncol, axis=1).reshape(B * ncol, nq)), np.ascontiguousarray(Qn))
+    X = np.concatenate([dQ, Vn], axis=1).reshape(B, nin, 2, nx)              # the base state cancels in the centred difference
+    D = (X[:, :, 0] - X[:, :, 1]) / (2.0 * eps)                              # [B, input, state']
+    A = np.ascontiguousarray(D[:, :nx].transpose(0, 2, 1))
+    Bm = np.ascontiguousarray(D[:, nx:].transpose(0, 2, 1))
+    return (A[0], Bm[0]) if B == 1 else (A, Bm)
 
 
 def linearize_discrete(model: Any, data: Any, use_native: bool = True, eps: float = 1e-6, horizon_steps: int = 1) -> tuple[np.ndarray, np.ndarray]:
-    if use_native:
+    if use_native:                                              # like the reference: the native path ignores horizon_steps
         try:
             return _native_transition_fd(model, data, eps=eps, centered=True)
-        except LinearizationError:
-            pass
+        except LinearizationError as exc:                       # not silently: the caller asked for the native path
+            import warnings
+
+            warnings.warn(f"native mjd_transitionFD failed ({exc}); using the finite-difference fallback", RuntimeWarning, stacklevel=2)
     return _fd_linearization(model, data, eps=eps, horizon_steps=horizon_steps)
 
 

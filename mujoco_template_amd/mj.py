@@ -240,6 +240,16 @@ class MjData:
         self._dev_newer = set(_DERIVED)
         self._check_engine_counters()
 
+    def float64_twin(self, batch: int) -> BatchSim:
+        """A float64 ``BatchSim`` of the same model / caps with ``batch`` environments, kept for reuse (the finite-difference
+        fallback of ``linearization.py`` steps its perturbed replicas there)."""
+        tw = self.__dict__.get("_twin")
+        if tw is None or tw.batch != int(batch):
+            s = self._sim
+            tw = BatchSim(self.model._device_model(), int(batch), dtype="float64", nconmax=s.nconmax, nefcmax=s.nefcmax, device=s.device)
+            object.__setattr__(self, "_twin", tw)
+        return tw
+
     def mark_device_newer(self, eager: bool = False) -> None:
         self._state_stale = True
         self._dev_newer = set(_DERIVED)

@@ -220,6 +220,171 @@ class _Defaults:
         return out
 
 
+
+# ----------------------------------------------------------------------------
+# schema: what the compiler honours, what it may ignore, and nothing else
+# ----------------------------------------------------------------------------
+# Every element / attribute is either HONOURED (read by the compiler below), IGNORABLE (rendering, naming and bookkeeping that
+# cannot change the physics of the supported subset) or REJECTED with an MjcfError naming it — a model outside the subset must
+# never simulate silently with different physics (<equality>, <option><flag>, frictionloss, ... were dropped unseen).
+_ORIENT = {"quat", "axisangle", "euler", "xyaxes", "zaxis"}
+_VISUAL_ATTRS = {"rgba", "material", "group"}                  # "group" of geoms / sites is a rendering group
+_SCHEMA_TOP = {"compiler", "option", "default", "worldbody", "tendon", "actuator", "sensor", "contact", "keyframe", "include",
+               # no physics in the supported subset:
+               "asset", "visual", "statistic", "size", "custom"}
+_SCHEMA_ATTRS: dict[str, tuple[set[str], set[str]]] = {
+    # tag: (honoured, ignorable)
+    "mujoco": ({"model"}, set()),
+    "compiler": ({"angle", "autolimits"}, {"meshdir", "texturedir", "assetdir", "strippath", "discardvisual", "balanceinertia", "boundmass",
+                                            "boundinertia", "fusestatic", "usethread", "alignfree"}),
+    "option": ({"timestep", "gravity", "integrator", "density", "viscosity", "impratio", "tolerance", "iterations", "cone", "solver",
+                "jacobian"}, {"ls_iterations", "ls_tolerance", "noslip_tolerance", "ccd_tolerance", "mpr_tolerance", "apirate"}),
+    "body": ({"name", "pos", "childclass"} | _ORIENT, {"user"}),
+    "joint": ({"name", "class", "type", "pos", "axis", "range", "limited", "damping", "stiffness", "armature", "margin", "ref", "springref",
+               "solreflimit", "solimplimit"}, {"group", "user"}),
+    "freejoint": ({"name"}, {"group"}),
+    "geom": ({"name", "class", "type", "size", "pos", "fromto", "contype", "conaffinity", "condim", "friction", "solref", "solimp", "solmix",
+              "margin", "gap", "priority", "density", "mass"} | _ORIENT, _VISUAL_ATTRS | {"user", "mesh", "fitscale"}),
+    "site": ({"name", "class", "pos"} | _ORIENT, _VISUAL_ATTRS | {"size", "type", "fromto", "user"}),
+    "fixed": ({"name", "class", "limited", "range", "margin", "solreflimit", "solimplimit"}, _VISUAL_ATTRS | {"user", "width"}),
+    "tendon/joint": ({"joint", "coef"}, set()),
+    "motor": ({"name", "class", "joint", "site", "gear", "ctrllimited", "ctrlrange", "forcelimited", "forcerange", "group"}, {"user"}),
+    "position": ({"name", "class", "joint", "site", "gear", "ctrllimited", "ctrlrange", "forcelimited", "forcerange", "group", "kp", "kv"}, {"user"}),
+    "general": ({"name", "class", "joint", "site", "gear", "ctrllimited", "ctrlrange", "forcelimited", "forcerange", "group", "dyntype",
+                 "gaintype", "biastype", "gainprm", "biasprm"}, {"user"}),
+    "jointpos": ({"name", "joint"}, {"noise", "cutoff", "user"}),
+    "gyro": ({"name", "site"}, {"noise", "cutoff", "user"}),
+    "accelerometer": ({"name", "site"}, {"noise", "cutoff", "user"}),
+    "framequat": ({"name", "objtype", "objname"}, {"noise", "cutoff", "user"}),
+    "exclude": ({"name", "body1", "body2"}, set()),
+    "key": ({"name", "qpos", "qvel", "ctrl", "time"}, set()),
+    "include": ({"file"}, set()),
+    "camera": (set(), None), "light": (set(), None),               # None: every attribute ignorable (rendering only)
+}
+# attributes whose NON-DEFAULT presence changes the physics and that the engine does not implement: named rejections
+_REJECT_ATTRS = {
+    "joint": {"frictionloss": "joint frictionloss", "actuatorfrcrange": "actuatorfrcrange", "actuatorfrclimited": "actuatorfrclimited",
+              "solreffriction": "joint friction constraints", "solimpfriction": "joint friction constraints", "springdamper": "springdamper"},
+    "geom": {"fluidshape": "ellipsoid fluid model", "fluidcoef": "ellipsoid fluid model"},
+    "body": {"mocap": "mocap bodies", "gravcomp": "gravity compensation"},
+    "fixed": {"frictionloss": "tendon frictionloss", "stiffness": "tendon springs", "damping": "tendon damping", "springlength": "tendon springs"},
+    "option": {"wind": "wind", "magnetic": None, "o_margin": "contact overrides", "o_solref": "contact overrides", "o_solimp": "contact overrides",
+               "o_friction": "contact overrides", "noslip_iterations": "the noslip solver", "actuatorgroupdisable": "actuatorgroupdisable (use opt.disableactuator)"},
+    "compiler": {"coordinate": None, "eulerseq": None, "settotalmass": "settotalmass", "inertiafromgeom": None, "inertiagrouprange": "inertiagrouprange"},
+}
+# rejected attributes that are harmless at these values (MuJoCo's defaults, or what the shipped models state explicitly)
+_REJECT_OK_VALUES = {("compiler", "coordinate"): {"local"}, ("compiler", "eulerseq"): {"xyz"}, ("compiler", "inertiafromgeom"): {"true", "auto"},
+                     ("compiler", "settotalmass"): {"-1"}, ("joint", "frictionloss"): {"0"}, ("fixed", "frictionloss"): {"0"},
+                     ("fixed", "stiffness"): {"0"}, ("fixed", "damping"): {"0"}, ("body", "mocap"): {"false"}, ("body", "gravcomp"): {"0"},
+                     ("option", "wind"): {"0 0 0"}, ("option", "noslip_iterations"): {"0"}, ("option", "magnetic"): None}     # None: any value
+
+
+def _check_attrs(tag: str, elem: ET.Element, where: str) -> None:
+    key = "tendon/joint" if (tag == "joint" and where == "tendon") else tag
+    if key not in _SCHEMA_ATTRS:
+        raise MjcfError(f"<{tag}> in <{where}> is outside the supported subset")
+    honoured, ignorable = _SCHEMA_ATTRS[key]
+    rejects = _REJECT_ATTRS.get(key, {})
+    for attr, val in elem.attrib.items():
+        if attr in honoured or ignorable is None or attr in ignorable:
+            continue
+        if attr in rejects:
+            ok = _REJECT_OK_VALUES.get((key, attr), set())
+            if ok is None or " ".join(val.split()) in ok or (ok and _is_float(val) and any(_is_float(o) and float(o) == float(val) for o in ok)):
+                continue
+            what = rejects[attr] or f"{attr}={val!r}"
+            raise MjcfError(f"<{tag} {attr}={val!r}>: {what} is outside the supported subset")
+        raise MjcfError(f"<{tag}> attribute {attr!r} is not recognised by this compiler (supported subset; it would be ignored silently otherwise)")
+
+
+def _is_float(text: str) -> bool:
+    try:
+        float(text)
+        return True
+    except ValueError:
+        return False
+
+
+def _validate_schema(root: ET.Element) -> None:
+    """Walk the (include-expanded) tree once and reject everything the compiler would otherwise drop without a word."""
+    _check_attrs("mujoco", root, "")
+    for sec in root:
+        if sec.tag not in _SCHEMA_TOP:
+            raise MjcfError(f"<{sec.tag}> is outside the supported subset (e.g. <equality> constraints, <deformable>, <extension> are not implemented)")
+        if sec.tag in ("asset", "visual", "statistic", "size", "custom"):
+            continue
+        if sec.tag == "compiler":
+            _check_attrs("compiler", sec, "mujoco")
+            for ch in sec:
+                raise MjcfError(f"<compiler><{ch.tag}> is outside the supported subset")
+        elif sec.tag == "option":
+            _check_attrs("option", sec, "mujoco")
+            for ch in sec:
+                if ch.tag != "flag":
+                    raise MjcfError(f"<option><{ch.tag}> is outside the supported subset")
+                for attr, val in ch.attrib.items():          # every flag must sit at MuJoCo's default: none of them is implemented as a switch
+                    default = "disable" if attr in ("override", "energy", "fwdinv", "invdiscrete", "multiccd", "island") else "enable"
+                    if val != default:
+                        raise MjcfError(f"<option><flag {attr}={val!r}>: option flags are outside the supported subset (all stay at MuJoCo's defaults)")
+        elif sec.tag == "default":
+            _validate_defaults(sec)
+        elif sec.tag == "worldbody":
+            _validate_body(sec, top=True)
+        elif sec.tag == "tendon":
+            for t in sec:
+                if t.tag != "fixed":
+                    raise MjcfError("only fixed tendons are inside the supported subset")
+                _check_attrs("fixed", t, "tendon")
+                for w in t:
+                    _check_attrs(w.tag, w, "tendon")
+        elif sec.tag == "actuator":
+            for e in sec:
+                if e.tag not in ("motor", "position", "general"):
+                    raise MjcfError(f"actuator <{e.tag}> is outside the supported subset")
+                _check_attrs(e.tag, e, "actuator")
+        elif sec.tag == "sensor":
+            for e in sec:
+                if e.tag not in ("jointpos", "gyro", "accelerometer", "framequat"):
+                    raise MjcfError(f"sensor <{e.tag}> is outside the supported subset")
+                _check_attrs(e.tag, e, "sensor")
+        elif sec.tag == "contact":
+            for e in sec:
+                if e.tag != "exclude":
+                    raise MjcfError("<contact><pair> is outside the supported subset")
+                _check_attrs("exclude", e, "contact")
+        elif sec.tag == "keyframe":
+            for e in sec:
+                if e.tag != "key":
+                    raise MjcfError(f"<keyframe><{e.tag}> is outside the supported subset")
+                _check_attrs("key", e, "keyframe")
+
+
+def _validate_defaults(elem: ET.Element) -> None:
+    for ch in elem:
+        if ch.tag == "default":
+            _validate_defaults(ch)
+        elif ch.tag in ("camera", "light", "material", "mesh"):
+            continue
+        elif ch.tag in ("joint", "geom", "site", "motor", "position", "general"):
+            _check_attrs(ch.tag, ch, "default")
+        elif ch.tag == "tendon":
+            _check_attrs("fixed", ch, "default")
+        else:
+            raise MjcfError(f"<default><{ch.tag}> is outside the supported subset")
+
+
+def _validate_body(elem: ET.Element, top: bool = False) -> None:
+    for ch in elem:
+        if ch.tag == "body":
+            _check_attrs("body", ch, "worldbody")
+            _validate_body(ch)
+        elif ch.tag in ("joint", "freejoint", "geom", "site", "camera", "light"):
+            _check_attrs(ch.tag, ch, "body")
+        elif ch.tag == "inertial":
+            raise MjcfError("<inertial> is outside the supported subset (inertia comes from geoms)")
+        else:
+            raise MjcfError(f"<{ch.tag}> inside a body is outside the supported subset")
+
 # ----------------------------------------------------------------------------
 # the compiler
 # ----------------------------------------------------------------------------
@@ -291,6 +456,7 @@ class _Compiler:
         root, m = self.root, self.m
         if root.tag != "mujoco":
             raise MjcfError("root element must be <mujoco>")
+        _validate_schema(root)
         for comp in root.findall("compiler"):
             ang = comp.get("angle")
             if ang == "radian":
@@ -433,6 +599,10 @@ class _Compiler:
                 size[2] = length / 2
         if gtype == GEOM_MESH:
             size[:] = 0.0
+            # meshes are accepted as VISUALS only: a mesh that should carry mass would need its volume (the .obj is never read)
+            if not ("mass" in a and float(a["mass"]) == 0.0):
+                raise MjcfError(f"mesh geom {a.get('name', '')!r} needs mass=\"0\": mesh inertia is outside the supported subset")
+
         solref = np.array(DEFAULT_SOLREF)
         if "solref" in a:
             v = _floats(a["solref"])

@@ -274,6 +274,7 @@ static int pair_maxcon(const mjoModel* m, int p) {
   int t1 = m->geom_type[m->pair_geom1[p]], t2 = m->geom_type[m->pair_geom2[p]];
   if (t1 == G_PLANE && t2 == G_CAPSULE) return 2;
   if (t1 == G_PLANE && t2 == G_BOX) return 4;
+  if (t1 == G_CAPSULE && t2 == G_CAPSULE) return 2;       /* parallel axes: up to two */
   return 1;
 }
 
@@ -736,28 +737,30 @@ static int sphere_capsule(const double* sp, double sr, const double* cp, const d
   addscl3(pt, cp, axis, x);
   return sphere_sphere(sp, sr, pt, size[0], margin, c);
 }
+/* mjraw_CapsuleCapsule [MJ-KNOWLEDGE: engine_collision_primitive.c]: nearest points of the two axis segments -> sphere-sphere.
+ * Parallel axes (|det| < mjMINVAL): MuJoCo tests the four end caps in the order (+end of 1, -end of 1, +end of 2, -end of 2);
+ * every end whose projection onto the OTHER segment falls inside it gives a sphere-sphere contact, at most two in total. */
 static int capsule_capsule(const double* p1, const double* m1, const double* s1, const double* p2, const double* m2, const double* s2, double margin, RawCon* c) {
   double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
   double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
   double det = ma * mc - mb * mb, x1, x2, v1[3], v2[3];
-  if (fabs(det) >= 1e-12) {
+  if (fabs(det) >= MINVAL) {
     x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det;
     if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; }
     else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb * s1[1]) / mc; }
     if (x2 > s2[1]) { x2 = s2[1]; x1 = (u - mb * s2[1]) / ma; if (x1 > s1[1]) x1 = s1[1]; if (x1 < -s1[1]) x1 = -s1[1]; }
     else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = (u + mb * s2[1]) / ma; if (x1 > s1[1]) x1 = s1[1]; if (x1 < -s1[1]) x1 = -s1[1]; }
-  } else { /* parallel axes: single contact at the midpoint of the overlap (documented simplification) */
-    double lo = -s1[1], hi = s1[1];      /* segment-1 parameter range overlapping the projection of segment 2 */
-    double c2 = -dot3(a1, dif);           /* centre of capsule 2 projected on axis 1 */
-    double sgn = mb < 0 ? 1.0 : -1.0;     /* a1.a2 sign */
-    double l2 = c2 - s2[1], h2 = c2 + s2[1];
-    if (l2 > lo) lo = l2; if (h2 < hi) hi = h2;
-    x1 = lo <= hi ? 0.5 * (lo + hi) : (c2 > 0 ? s1[1] : -s1[1]);
-    x2 = sgn * (x1 - c2);
-    if (x2 > s2[1]) x2 = s2[1]; if (x2 < -s2[1]) x2 = -s2[1];
+    addscl3(v1, p1, a1, x1); addscl3(v2, p2, a2, x2);
+    return sphere_sphere(v1, s1[0], v2, s2[0], margin, c);
   }
-  addscl3(v1, p1, a1, x1); addscl3(v2, p2, a2, x2);
-  return sphere_sphere(v1, s1[0], v2, s2[0], margin, c);
+  int n = 0;
+  for (int k = 0; k < 4 && n < 2; k++) {
+    if (k < 2) { x1 = k == 0 ? s1[1] : -s1[1]; x2 = (v - mb * x1) / mc; if (x2 < -s2[1] || x2 > s2[1]) continue; }
+    else { x2 = k == 2 ? s2[1] : -s2[1]; x1 = (u - mb * x2) / ma; if (x1 < -s1[1] || x1 > s1[1]) continue; }
+    addscl3(v1, p1, a1, x1); addscl3(v2, p2, a2, x2);
+    n += sphere_sphere(v1, s1[0], v2, s2[0], margin, c + n);
+  }
+  return n;
 }
 
 static void collision(const mjoModel* m, mjoData* d) {

@@ -48,6 +48,20 @@ def models():
     return MODELS
 
 
+# two capsules with PARALLEL axes, the shorter one (half-length 0.2, r 0.04) lying 5 mm inside the longer one (0.3, r 0.05),
+# 0.05 off-centre: MuJoCo's parallel branch gives two contacts, at the two ends of the shorter capsule (hand-derived in
+# tests/test_oracle_anchors.py::test_parallel_capsules_give_two_contacts)
+CAPSULES_XML = """
+<mujoco model="parallel-capsules">
+  <option timestep="0.002"/>
+  <worldbody>
+    <body name="a" pos="0 0 1"><freejoint/><geom name="ga" type="capsule" size="0.05" fromto="-0.3 0 0 0.3 0 0"/></body>
+    <body name="b" pos="0.05 0 1.085"><freejoint/><geom name="gb" type="capsule" size="0.04" fromto="-0.2 0 0 0.2 0 0"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
 @pytest.fixture(scope="session")
 def compiled():
     from mujoco_template_amd.mjcf import compile_xml_path

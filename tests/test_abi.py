@@ -89,3 +89,39 @@ def test_specialised_kernel_source_and_cross_compile():
     blob = open(path, "rb").read()
     assert (blob[:4] == b"\x7fELF" or blob.startswith(b"__CLANG_OFFLOAD_BUNDLE__")) and b"mjb_k_step_spec" in blob and b"gfx950" in blob
     assert compile_spec(src) == path                      # cached
+
+
+def test_spec_scheduler_rule_and_private_cache(tmp_path, monkeypatch):
+    """VERDICT r1 #7 / ADVICE r1: the scheduler of the specialised kernel follows a stated rule (iterative ILP only for
+    one-wave-per-environment kernels; ROCm 7.2.0's clang crashes with it on the packed BASE_XML kernel,
+    profiles/r02_hipcc_iterative_ilp_crash.txt), and the fallback cache of a read-only install is private."""
+    import stat
+
+    import torch  # noqa: F401
+
+    from mujoco_template_amd import _capi, mjcf
+    from mujoco_template_amd._capi import DeviceModel, compile_spec, spec_scheduler
+    from tests.conftest import BASE_XML, MODELS
+
+    assert spec_scheduler(DeviceModel(mjcf.compile_xml_path(MODELS["humanoid"])).spec_source()) == "iterative-ilp"
+    base_src = DeviceModel(mjcf.compile_xml_string(BASE_XML)).spec_source()
+    assert "#define MJB_SPEC_G 8" in base_src and spec_scheduler(base_src) is None
+    assert os.path.exists(compile_spec(base_src))                 # the crashing case compiles under the rule (cross-compile only)
+    # read-only install: the cache moves to a 0700 directory under the user's cache home; a planted world-writable one is refused
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path))
+    d = _capi._private_cache_dir()
+    assert d.startswith(str(tmp_path)) and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    os.chmod(d, 0o777)
+    with pytest.raises(_capi.TemplateError, match="refusing"):
+        _capi._private_cache_dir()
+    os.chmod(d, 0o700)
+    planted = os.path.join(d, "k_step_spec_x.hsaco")
+    with open(planted, "wb") as fh:
+        fh.write(b"x")
+    os.chmod(planted, 0o666)
+    with pytest.raises(_capi.TemplateError, match="refusing"):
+        _capi._read_private(planted)
+    link = os.path.join(d, "link.hsaco")
+    os.symlink(planted, link)
+    with pytest.raises(OSError):
+        _capi._read_private(link)

@@ -475,3 +475,39 @@ def test_binary_model_steps_like_the_xml_model(tmp_path):
         h.data.ctrl[:] = 4.0
         h.step(20)
     assert np.array_equal(a.data.qpos, b.data.qpos) and np.array_equal(a.data.qvel, b.data.qvel)
+
+
+def test_fd_fallback_is_float64_batched_and_matches_native_away_from_zero():
+    """the Python FD fallback used to nudge the fp32 device state by eps = 1e-6 (8 ulps of an O(1) state) and refused
+    batches.  Now: a float64 twin, all replicas in one launch, any batch, horizon_steps; at a NON-ZERO state it agrees with the
+    native mjd_transitionFD to 1e-4 relative, and a 3-step horizon equals the chain of three one-step linearisations."""
+    rng = np.random.default_rng(4)
+    for name, B in (("cartpole", 3), ("drone2", 2)):
+        h = mt.ModelHandle.from_xml_path(MODELS[name], batch=B, dtype="float32")
+        m, d = h.model, h.data
+        q = np.array(d.qpos)
+        if name == "cartpole":
+            q[:] = rng.uniform(-0.4, 0.4, size=q.shape)
+        else:
+            q[:, 2] += 0.5 + rng.uniform(0, 0.2, size=B)                         # airborne: smooth dynamics
+        d.qpos[:] = q
+        d.qvel[:] = rng.normal(size=d.qvel.shape) * 0.3
+        d.ctrl[:] = 2.0 if name == "drone2" else rng.uniform(-20, 20, size=d.ctrl.shape)
+        h.forward()
+        before = np.array(d.qpos), np.array(d.qvel)
+        A1, B1 = mt.linearize_discrete(m, d, use_native=True)
+        A2, B2 = mt.linearize_discrete(m, d, use_native=False)
+        assert A2.shape == (B, 2 * m.nv, 2 * m.nv) and B2.shape == (B, 2 * m.nv, m.nu)
+        assert np.abs(A1 - A2).max() <= 1e-4 * max(1.0, np.abs(A1).max()) and np.abs(B1 - B2).max() <= 1e-4 * max(1.0, np.abs(B1).max())
+        assert np.array_equal(d.qpos, before[0]) and np.array_equal(d.qvel, before[1])       # data untouched
+        # horizon: d x_3 / d x_0 = A(x_2) A(x_1) A(x_0) along the trajectory (float64 data so that the chain is exact to FD error)
+        h64 = mt.ModelHandle.from_xml_path(MODELS[name], batch=B, dtype="float64")
+        h64.data.qpos[:] = before[0]; h64.data.qvel[:] = before[1]; h64.data.ctrl[:] = d.ctrl
+        h64.forward()
+        A3, _ = mt.linearize_discrete(h64.model, h64.data, use_native=False, horizon_steps=3)
+        chain = np.tile(np.eye(2 * m.nv), (B, 1, 1))
+        for _ in range(3):
+            Ak, _ = mt.linearize_discrete(h64.model, h64.data, use_native=True)
+            chain = Ak @ chain
+            h64.step()
+        assert np.abs(A3 - chain).max() <= 2e-4 * max(1.0, np.abs(chain).max())

@@ -85,6 +85,33 @@ def test_forward_phases_match_oracle(world, name, dtype):
             assert typ[e, :n].tolist() == od.efc_type().tolist()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_parallel_capsules_two_contacts(dtype):
+    """mjraw_CapsuleCapsule with parallel axes: two end-cap contacts (hand-derived in tests/test_oracle_anchors.py); the fp32 kernel
+    takes the parallel branch for axes within 1e-3 rad (it cannot resolve the float64 |det| < 1e-15 test)."""
+    from tests.conftest import CAPSULES_XML
+
+    cm = mjcf.compile_xml_string(CAPSULES_XML)
+    om, dm = mjo.OracleModel(cm), DeviceModel(cm)
+    od = mjo.OracleData(om)
+    od.forward()
+    sim = BatchSim(dm, 3, dtype=dtype)
+    sim.debug_forward()
+    cn = sim.counters()
+    assert cn["ncon"].tolist() == [2, 2, 2] and cn["nefc"].tolist() == [8, 8, 8]
+    con = sim.debug_get("con").reshape(3, sim.nconmax, 11)[0, :2]
+    ref = od.contacts()
+    tol = 1e-12 if dtype == "float64" else 2e-7
+    assert np.abs(con[:, 0] - ref["dist"]).max() <= tol and np.abs(con[:, 1:4] - ref["pos"]).max() <= tol
+    assert sorted(con[:, 1].tolist()) == pytest.approx([-0.15, 0.25], abs=tol)            # the hand-derived anchor
+    J = sim.debug_get("efc_J").reshape(3, sim.nefcmax, cm.nv)[0, :8]
+    assert np.abs(J - od.efc_J.reshape(8, cm.nv)).max() <= (1e-12 if dtype == "float64" else 1e-6)
+    sim.step(20)
+    for _ in range(20):
+        od.step()
+    assert np.abs(sim.get("qpos")[0] - od.qpos).max() <= (1e-10 if dtype == "float64" else 2e-5)
+
+
 @pytest.mark.parametrize("name,steps", [("pendulum", 200), ("cartpole", 200), ("drone2", 100), ("humanoid", 150)])
 def test_float64_free_running_matches_oracle(world, name, steps):
     """Same kernels in double: rounding-level agreement over whole trajectories, contacts included."""

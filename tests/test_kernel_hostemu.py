@@ -157,3 +157,20 @@ def test_more_bodies_than_lanes_takes_the_slow_tree_paths():
     for _ in range(30):
         od.step(); e.step()
     assert np.abs(e.qpos - od.qpos).max() < 1e-10 and np.abs(e.qvel - od.qvel).max() < 1e-9
+
+
+def test_parallel_capsules_two_contacts_in_the_kernel_source():
+    """The kernel's mjraw_CapsuleCapsule parallel branch (two end-cap contacts) against the oracle and the hand-derived anchor."""
+    from mujoco_template_amd import mjcf
+    from tests.conftest import CAPSULES_XML
+
+    cm = mjcf.compile_xml_string(CAPSULES_XML)
+    od = mjo.OracleData(mjo.OracleModel(cm))
+    e = EmuEnv(cm, G=16, use_double=True)
+    od.forward(); e.forward()
+    assert e.counters[0] == 2 and e.counters[1] == 8 == od.counters()["nefc"]
+    assert np.abs(e.efc_J[: 8 * cm.nv] - od.efc_J).max() < 1e-12
+    assert np.abs(e.qacc - od.qacc).max() < 1e-9 * max(1.0, np.abs(od.qacc).max())
+    for s in range(5):
+        od.step(); e.step()
+    assert np.abs(e.qpos - od.qpos).max() < 1e-11

@@ -115,3 +115,186 @@ def test_errors():
         mjcf.compile_xml_path("/nonexistent/model.xml")
     with pytest.raises(mjcf.MjcfError):   # moving body without mass
         mjcf.compile_xml_string("<mujoco><worldbody><body><joint/></body></worldbody></mujoco>")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Independent anchors for what the oracle and the HIP path SHARE (both consume mjcf.compile_xml_path's output, so a compiler error
+# is invisible to every parity test; VERDICT r1 "Next round" #2).  Every expected value below is derived from numbers
+# transcribed BY HAND from the XML with textbook closed forms written here — no compiler function is called to produce it.
+# ------------------------------------------------------------------------------------------------------------------------------
+def _capsule_mass(r, length, rho=1000.0):
+    return rho * (math.pi * r * r * length + 4.0 / 3.0 * math.pi * r ** 3)
+
+
+def _capsule_inertia_about_com(r, length, rho=1000.0):
+    """(I_transverse, I_axial) of a solid capsule: cylinder of the given length + two hemispherical caps (textbook)."""
+    mc, ms = rho * math.pi * r * r * length, rho * 4.0 / 3.0 * math.pi * r ** 3
+    i_ax = 0.5 * mc * r * r + 0.4 * ms * r * r
+    i_tr = mc * (length ** 2 / 12.0 + r * r / 4.0) + ms * (0.4 * r * r + length ** 2 / 4.0 + 3.0 / 8.0 * length * r)
+    return i_tr, i_ax
+
+
+def test_humanoid_masses_and_inertias_from_fromto_capsules_and_nested_defaults(compiled):
+    """humanoid.xml:35-104: geoms inherit type=capsule from class "body" (childclass of the torso), their radius from the nested
+    classes thigh / shin / foot / arm_upper / arm_lower, the shin and the feet even their fromto; hands are spheres (class hand)."""
+    m = compiled("humanoid")
+    seg = lambda a, b: math.dist(a, b)                                   # noqa: E731
+    # (radius, length) transcribed from the XML, body by body; spheres as (radius, None)
+    geoms = {
+        "torso": [(0.07, 0.14), (0.06, 0.12)], "head": [(0.09, None)], "waist_lower": [(0.06, 0.12)], "pelvis": [(0.09, 0.14)],
+        "thigh_right": [(0.06, seg((0, 0, 0), (0, 0.01, -0.34)))], "shin_right": [(0.049, 0.3)],
+        "foot_right": [(0.027, seg((-0.07, -0.01, 0), (0.14, -0.03, 0))), (0.027, seg((-0.07, 0.01, 0), (0.14, 0.03, 0)))],
+        "thigh_left": [(0.06, seg((0, 0, 0), (0, -0.01, -0.34)))], "shin_left": [(0.049, 0.3)],
+        "foot_left": [(0.027, seg((-0.07, -0.01, 0), (0.14, -0.03, 0))), (0.027, seg((-0.07, 0.01, 0), (0.14, 0.03, 0)))],
+        "upper_arm_right": [(0.04, seg((0, 0, 0), (0.16, -0.16, -0.16)))], "lower_arm_right": [(0.031, seg((0.01, 0.01, 0.01), (0.17, 0.17, 0.17)))],
+        "hand_right": [(0.04, None)],
+        "upper_arm_left": [(0.04, seg((0, 0, 0), (0.16, 0.16, -0.16)))], "lower_arm_left": [(0.031, seg((0.01, -0.01, 0.01), (0.17, -0.17, 0.17)))],
+        "hand_left": [(0.04, None)],
+    }
+    total = 0.0
+    for body, gl in geoms.items():
+        mass = sum(_capsule_mass(r, ln) if ln is not None else 1000.0 * 4.0 / 3.0 * math.pi * r ** 3 for r, ln in gl)
+        total += mass
+        assert m.body_mass[m.name2id(mjcf.OBJ_BODY, body)] == pytest.approx(mass, rel=1e-12), body
+    assert m.body_mass.sum() == pytest.approx(total, rel=1e-12) and total == pytest.approx(40.8446, abs=1e-3)
+    # shin (class "shin": BOTH fromto and size come from the default class): principal inertia of one capsule along z
+    b = m.name2id(mjcf.OBJ_BODY, "shin_right")
+    i_tr, i_ax = _capsule_inertia_about_com(0.049, 0.3)
+    assert sorted(m.body_inertia[b]) == pytest.approx(sorted([i_tr, i_tr, i_ax]), rel=1e-12)
+    assert m.body_ipos[b] == pytest.approx([0, 0, -0.15], abs=1e-15)
+    # hand: sphere through class "hand" (type overridden inside the capsule class), zaxis attribute irrelevant for a sphere
+    b = m.name2id(mjcf.OBJ_BODY, "hand_left")
+    assert m.body_inertia[b] == pytest.approx([0.4 * 1000 * 4 / 3 * math.pi * 0.04 ** 5] * 3, rel=1e-12)
+    # foot: two capsules splayed by +-atan(0.02/0.21) about z, centres at (0.035, -+0.02, 0): parallel-axis theorem by hand
+    b = m.name2id(mjcf.OBJ_BODY, "foot_right")
+    ln = seg((-0.07, -0.01, 0), (0.14, -0.03, 0))
+    mf = _capsule_mass(0.027, ln)
+    i_tr, i_ax = _capsule_inertia_about_com(0.027, ln)
+    th = math.atan2(0.02, 0.21)
+    c2, s2 = math.cos(th) ** 2, math.sin(th) ** 2
+    ixx = 2 * (i_ax * c2 + i_tr * s2 + mf * 0.02 ** 2)            # the xy products of the two mirrored capsules cancel
+    iyy = 2 * (i_ax * s2 + i_tr * c2)
+    izz = 2 * (i_tr + mf * 0.02 ** 2)
+    assert m.body_ipos[b] == pytest.approx([0.035, 0, 0], abs=1e-15)
+    assert sorted(m.body_inertia[b]) == pytest.approx(sorted([ixx, iyy, izz]), rel=1e-10)
+    # upper arm along (1,-1,-1)/sqrt3: inertia frame = capsule frame, com at the segment midpoint
+    b = m.name2id(mjcf.OBJ_BODY, "upper_arm_right")
+    i_tr, i_ax = _capsule_inertia_about_com(0.04, seg((0, 0, 0), (0.16, -0.16, -0.16)))
+    assert sorted(m.body_inertia[b]) == pytest.approx(sorted([i_tr, i_tr, i_ax]), rel=1e-10)
+    assert m.body_ipos[b] == pytest.approx([0.08, -0.08, -0.08], abs=1e-15)
+
+
+def test_cartpole_invweight0_closed_form(compiled):
+    """dof_invweight0 = diag(M^-1), body_invweight0 = tr(J M^-1 J^T)/3 (translation, rotation) at qpos0 — the constants that scale
+    every constraint row's regulariser R.  Cart-pole by hand (cartpole.xml:18-27): M = [[mc+mp, mp l], [mp l, I_h]] at theta = 0."""
+    m = compiled("cartpole")
+    mc = 500.0 * 0.24 * 0.4 * 0.1                                           # box 0.12 x 0.2 x 0.05 half-sizes, density 500
+    r, ln, rho = 0.025, 0.6, 300.0
+    mp = _capsule_mass(r, ln, rho)
+    i_tr, _ = _capsule_inertia_about_com(r, ln, rho)
+    l = 0.3                                                                  # com of the pole above the hinge
+    ih = i_tr + mp * l * l
+    mt = mc + mp
+    det = mt * ih - (mp * l) ** 2
+    minv = np.array([[ih, -mp * l], [-mp * l, mt]]) / det
+    assert m.dof_invweight0 == pytest.approx([minv[0, 0], minv[1, 1]], rel=1e-10)
+    cart, pole = m.name2id(mjcf.OBJ_BODY, "cart"), m.name2id(mjcf.OBJ_BODY, "pole")
+    assert m.body_invweight0[cart, 0] == pytest.approx(minv[0, 0] / 3, rel=1e-10)          # J_p = [1 0]: x only
+    jp = np.array([1.0, l])                                                  # com velocity of the pole along x: xdot + l thetadot
+    assert m.body_invweight0[pole, 0] == pytest.approx(jp @ minv @ jp / 3, rel=1e-10)
+    assert m.body_invweight0[pole, 1] == pytest.approx(minv[1, 1] / 3, rel=1e-10)          # rotation about y only
+    assert m.body_invweight0[cart, 1] <= 1e-12                                              # the cart cannot rotate
+
+
+def test_humanoid_tendon_limit_row_by_hand(compiled):
+    """Fixed tendon hamstring_right (humanoid.xml:192-195): length = 0.5 q_hip_y - 0.5 q_knee, range [-0.3, 2].  With hip_y = -1 rad
+    the lower limit is violated by 0.2: one row J = +[0.5, -0.5] on the two dofs, pos = -0.2, and with the default solref (0.02, 1) /
+    solimp (0.9, 0.95, 0.001, 0.5, 2): K = 1 / (0.95^2 0.02^2), B = 2 / (0.95 0.02), impedance = dmax = 0.95 (|pos| >> width)
+    => aref = -B J.v - K imp pos, R = (1 - imp) / imp * tendon_invweight0, tendon_invweight0 = J M0^-1 J^T."""
+    from oracle import mjo
+
+    m = compiled("humanoid")
+    od = mjo.OracleData(mjo.OracleModel(m))
+    jh, jk = m.name2id(mjcf.OBJ_JOINT, "hip_y_right"), m.name2id(mjcf.OBJ_JOINT, "knee_right")
+    od.qpos[2] = 2.0                                                         # lift it: no floor contacts
+    od.qpos[m.jnt_qposadr[jh]] = -1.0
+    od.qvel[m.jnt_dofadr[jh]] = 0.4
+    od.qvel[m.jnt_dofadr[jk]] = -0.6
+    od.forward()
+    typ = od.efc_type()
+    rows = [i for i in range(len(typ)) if typ[i] == 1]                        # EFC_LIMIT_TENDON
+    assert len(rows) == 1
+    r = rows[0]
+    J = od.efc_J.reshape(-1, m.nv)[r]
+    want = np.zeros(m.nv); want[m.jnt_dofadr[jh]] = 0.5; want[m.jnt_dofadr[jk]] = -0.5
+    assert J == pytest.approx(want, abs=1e-15)
+    assert od.efc_pos[r] == pytest.approx(-0.5 + 0.3, abs=1e-15)
+    K, B, imp = 1.0 / (0.95 ** 2 * 0.02 ** 2), 2.0 / (0.95 * 0.02), 0.95
+    assert od.efc_aref[r] == pytest.approx(-B * (0.5 * 0.4 - 0.5 * -0.6) - K * imp * -0.2, rel=1e-12)
+    tinv = want @ np.linalg.solve(m.qM0, want)                               # J M0^-1 J^T with the mass matrix at qpos0
+    assert od.efc_D[r] == pytest.approx(imp / ((1 - imp) * tinv), rel=1e-9)
+
+
+def test_base_xml_position_servo_by_hand():
+    """<position joint="hinge" ctrlrange="-0.5 0.5"> (reference tests/test_mujoco_template.py:55): kp defaults to 1, force = kp (u - q)
+    with u clamped to the ctrlrange; the motor beside it is force-limited to +-10.  qfrc_actuator = sum of both (gear 1)."""
+    from oracle import mjo
+
+    m = mjcf.compile_xml_string(BASE_XML)
+    od = mjo.OracleData(mjo.OracleModel(m))
+    od.qpos[0] = 0.01
+    od.ctrl[:] = [25.0, 0.8]                                                 # motor saturates at 10, servo target clamps to 0.5
+    od.forward()
+    assert od.qfrc_actuator[0] == pytest.approx(10.0 + 1.0 * (0.5 - 0.01), rel=1e-14)
+    od.ctrl[:] = [-3.0, -0.2]
+    od.forward()
+    assert od.qfrc_actuator[0] == pytest.approx(-3.0 + 1.0 * (-0.2 - 0.01), rel=1e-14)
+
+
+_REJECTS = {
+    "equality": ('<equality><weld body1="torso"/></equality>', "equality"),
+    "flag": ('<option><flag gravity="disable"/></option>', "flag"),
+    "contact flag": ('<option><flag contact="disable"/></option>', "flag"),
+    "frictionloss": None,
+    "noslip": ('<option noslip_iterations="3"/>', "noslip"),
+    "override": ('<option o_margin="0.01"/>', "override"),
+    "wind": ('<option wind="1 0 0"/>', "wind"),
+    "eulerseq": ('<compiler eulerseq="zyx"/>', "eulerseq"),
+    "settotalmass": ('<compiler settotalmass="5"/>', "settotalmass"),
+    "global coordinates": ('<compiler coordinate="global"/>', "coordinate"),
+    "unknown section": ('<deformable/>', "deformable"),
+    "unknown option": ('<option banana="1"/>', "banana"),
+    "contact pair": ('<contact><pair geom1="torso_geom" geom2="torso_geom"/></contact>', "pair"),
+    "velocity actuator": ('<actuator><velocity joint="hinge"/></actuator>', "velocity"),
+    "touch sensor": ('<sensor><touch site="tip"/></sensor>', "touch"),
+}
+
+
+@pytest.mark.parametrize("what", [k for k, v in _REJECTS.items() if v is not None])
+def test_unsupported_mjcf_is_rejected_loudly(what):
+    """anything outside the supported subset raises MjcfError naming it — never a silent drop (a model with <equality>,
+    <flag gravity=disable> and frictionloss used to compile and simulate different physics without a word)."""
+    snippet, needle = _REJECTS[what]
+    xml = BASE_XML.replace("</mujoco>", snippet + "\n</mujoco>")
+    with pytest.raises(mjcf.MjcfError, match=needle):
+        mjcf.compile_xml_string(xml)
+
+
+def test_unsupported_mjcf_attributes_are_rejected_loudly():
+    for old, new, needle in (
+        ('<joint name="hinge" type="hinge" axis="0 0 1"/>', '<joint name="hinge" type="hinge" axis="0 0 1" frictionloss="0.1"/>', "frictionloss"),
+        ('<joint name="hinge" type="hinge" axis="0 0 1"/>', '<joint name="hinge" type="hinge" axis="0 0 1" wobble="1"/>', "wobble"),
+        ('<geom name="torso_geom" type="capsule" size="0.04 0.2" pos="0 0 0"/>', '<geom name="torso_geom" type="capsule" size="0.04 0.2" fluidshape="ellipsoid"/>', "fluid"),
+        ('<geom name="torso_geom" type="capsule" size="0.04 0.2" pos="0 0 0"/>', '<geom name="torso_geom" type="mesh" mesh="m" contype="0" conaffinity="0"/>', "mesh"),
+        ('<body name="torso">', '<body name="torso" gravcomp="1">', "gravity compensation"),
+        ('<body name="torso">', '<body name="torso" mocap="true">', "mocap"),
+        ('<joint limited="true" range="-1 1"/>', '<joint limited="true" range="-1 1" frictionloss="2"/>', "frictionloss"),     # in <default>
+    ):
+        assert old in BASE_XML
+        with pytest.raises(mjcf.MjcfError, match=needle):
+            mjcf.compile_xml_string(BASE_XML.replace(old, new))
+    # harmless values of the same attributes (MuJoCo's defaults) and rendering-only content still compile
+    ok = BASE_XML.replace('<joint name="hinge" type="hinge" axis="0 0 1"/>', '<joint name="hinge" type="hinge" axis="0 0 1" frictionloss="0"/>')
+    ok = ok.replace("<worldbody>", '<visual><global offwidth="800"/></visual><option><flag gravity="enable"/></option><worldbody><light pos="0 0 3"/>')
+    ok = ok.replace('<geom name="torso_geom"', '<geom rgba="1 0 0 1" name="torso_geom"')
+    assert mjcf.compile_xml_string(ok).nv == 1

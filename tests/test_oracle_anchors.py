@@ -313,3 +313,31 @@ def test_k1b_inverse_dynamics_anchors(oracle):
     assert od.counters()["nefc"] > 0
     od.inverse()
     assert np.abs(od.qfrc_inverse - od.qfrc_actuator).max() < 1e-6 * max(1.0, np.abs(od.qfrc_actuator).max())
+
+
+def test_parallel_capsules_give_two_contacts():
+    """MuJoCo's mjraw_CapsuleCapsule, parallel axes: the end caps are tested in the order (+1, -1 of capsule 1, +1, -1 of capsule 2)
+    and every end that projects inside the other segment gives a sphere-sphere contact, at most two (the
+    restatement gave ONE contact at the overlap midpoint).  Hand-derived for tests/conftest.py CAPSULES_XML: capsule 1 centre
+    (0,0,1), half-length 0.3, r 0.05; capsule 2 centre (0.05,0,1.085), half-length 0.2, r 0.04, both along x.
+      ends of 1 (x = +-0.3) project to x2 = +0.25 / -0.35: outside [-0.2, 0.2] -> no contact;
+      ends of 2 (world x = 0.25 / -0.15) project to x1 = 0.25 / -0.15: inside [-0.3, 0.3] -> two contacts;
+      each: centre distance 0.085, dist = 0.085 - 0.09 = -0.005, normal +z (1 -> 2), pos = c1 + n (r1 + dist/2) = (x, 0, 1.0475)."""
+    from mujoco_template_amd import mjcf
+    from tests.conftest import CAPSULES_XML
+
+    cm = mjcf.compile_xml_string(CAPSULES_XML)
+    om = mjo.OracleModel(cm)
+    od = mjo.OracleData(om)
+    od.forward()
+    con = od.contacts()
+    assert od.counters()["ncon"] == 2
+    assert sorted(con["pos"][:, 0].tolist()) == pytest.approx([-0.15, 0.25], abs=1e-12)
+    assert con["dist"] == pytest.approx([-0.005, -0.005], abs=1e-12)
+    assert con["pos"][:, 1:] == pytest.approx(np.array([[0.0, 1.0475]] * 2), abs=1e-12)
+    assert np.abs(con["frame"][:, 0]) == pytest.approx(np.array([[0, 0, 1.0]] * 2), abs=1e-12)
+    assert od.counters()["nefc"] == 8                            # two condim-3 contacts -> 2 x 4 pyramidal rows
+    # tilting capsule 2 by 1e-3 rad leaves the parallel branch: one contact, at the nearest point pair
+    od.qpos[7 + 3:7 + 7] = [np.cos(5e-4), 0, np.sin(5e-4), 0]    # rotation about y
+    od.forward()
+    assert od.counters()["ncon"] == 1
