@@ -36,7 +36,10 @@ def _fd_linearization(model: Any, data: Any, eps: float = 1e-6, horizon_steps: i
     nudged by +-eps), batched: all ``2 (2 nv + nu)`` perturbed replicas of all environments advance together in ONE fused
     launch of a temporary FLOAT64 twin of ``data`` (eps = 1e-6 differences are meaningless in fp32: ADVICE r1), the tangent-space
     differences are formed by the batched ``mjb_integrate_pos`` / ``mjb_differentiate_pos``.  ``data`` itself is not touched.
-    Position rows use the native sign convention."""
+    Position rows use the native sign convention.  Like the reference's fallback, dq' is measured from the BASE
+    qpos (``_dqpos(after, base)``), whereas ``mjd_transitionFD`` differences the two perturbed NEXT states directly: for a free body
+    spinning at ``w`` the two rotation blocks differ by the antisymmetric ``1/2 [w h]x`` (second order in the step; measured 2.5e-3 on
+    the drone at |w| = 0.5 rad/s) — a property of the reference's two code paths, reproduced, not a discrepancy of this engine."""
     if horizon_steps < 1:
         raise LinearizationError("horizon_steps must be >= 1")
     if not eps > 0:

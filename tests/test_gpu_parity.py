@@ -106,10 +106,13 @@ def test_parallel_capsules_two_contacts(dtype):
     assert sorted(con[:, 1].tolist()) == pytest.approx([-0.15, 0.25], abs=tol)            # the hand-derived anchor
     J = sim.debug_get("efc_J").reshape(3, sim.nefcmax, cm.nv)[0, :8]
     assert np.abs(J - od.efc_J.reshape(8, cm.nv)).max() <= (1e-12 if dtype == "float64" else 1e-6)
-    sim.step(20)
-    for _ in range(20):
+    # float64 follows the oracle through the |det| < 1e-15 switch step after step; fp32 keeps the two-contact branch while the axes
+    # stay within 1e-3 rad (the oracle leaves it after the first step's 1e-10 rad of relative rotation), so only ONE step is compared
+    nstep = 20 if dtype == "float64" else 1
+    sim.step(nstep)
+    for _ in range(nstep):
         od.step()
-    assert np.abs(sim.get("qpos")[0] - od.qpos).max() <= (1e-10 if dtype == "float64" else 2e-5)
+    assert np.abs(sim.get("qpos")[0] - od.qpos).max() <= (1e-10 if dtype == "float64" else 2e-6)
 
 
 @pytest.mark.parametrize("name,steps", [("pendulum", 200), ("cartpole", 200), ("drone2", 100), ("humanoid", 150)])
