@@ -139,6 +139,13 @@ int mjb_rollout(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned st
 /* gains of MJB_CTRL_FEEDBACK, host float64: K [nu, 2nv] row-major, u0 [nu], q0 [nq], v0 [nv] (NULL = zeros); shared by all environments */
 int mjb_set_feedback(mjbData* d, const double* K, const double* u0, const double* q0, const double* v0);
 
+/* the same law as a STANDALONE batched kernel for the host-driven loop (one K for many environments: K dx is a GEMM [batch, 2nv] x
+ * [2nv, nu], on MFMA in fp32): writes data.ctrl on the device from the current qpos / qvel, then the host calls mjb_step / mjb_step_host.
+ * Optional ctrl noise of the reference law (lqr.py:160-165): ctrl += std[a] * table[(step + env * env_stride) mod nsteps][a] before the
+ * clip (also inside MJB_CTRL_FEEDBACK rollouts, step = the rollout's step counter); mjb_set_feedback_noise(d, NULL, NULL, 0, 0) switches it off.  Host float64 inputs: std [nu], table [nsteps, nu]. */
+int mjb_set_feedback_noise(mjbData* d, const double* noise_std, const double* noise_table, int nsteps, int env_stride);
+int mjb_feedback_ctrl(mjbData* d, int step);
+
 /* ---- observations: ObservationExtractor.__call__ with as_dict=False (reference observations.py:98-174) ---- */
 int mjb_obs_spec_create(mjbData* d, int flags, int nsite, const int* site_ids, int nbody, const int* body_ids,
                         int ngeom, const int* geom_ids, int nsubtree, const int* subtree_ids, mjbObsSpec** out);

@@ -79,6 +79,10 @@ def load_library() -> ctypes.CDLL:
     L.mjb_rollout.argtypes = [vp, ci, ci, cu, cu, cd, vp, vp, ci]
     L.mjb_set_feedback.argtypes = [vp, vp, vp, vp, vp]
     L.mjb_set_feedback.restype = ci
+    L.mjb_set_feedback_noise.argtypes = [vp, vp, vp, ci, ci]
+    L.mjb_set_feedback_noise.restype = ci
+    L.mjb_feedback_ctrl.argtypes = [vp, ci]
+    L.mjb_feedback_ctrl.restype = ci
     L.mjb_obs_spec_create.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, ci, vp, pvp]
     L.mjb_obs_spec_free.argtypes = [vp]
     L.mjb_obs_dim.argtypes = [vp]
@@ -531,6 +535,22 @@ class BatchSim:
         if K.shape != (m.nu, 2 * m.nv) or u0.shape != (m.nu,) or q0.shape != (m.nq,) or v0.shape != (m.nv,):
             raise ConfigError("feedback gains must have shapes K [nu, 2nv], u0 [nu], q0 [nq], v0 [nv]")
         _check(load_library().mjb_set_feedback(self.ptr, K.ctypes.data, u0.ctypes.data, q0.ctypes.data, v0.ctypes.data))
+
+    def set_feedback_noise(self, std: np.ndarray | None, table: np.ndarray | None, env_stride: int = 0) -> None:
+        """ctrl noise of the feedback law: ``+ std[a] * table[(step + env * env_stride) % nsteps, a]`` before the clip; None switches it off."""
+        if std is None or table is None:
+            _check(load_library().mjb_set_feedback_noise(self.ptr, None, None, 0, 0))
+            return
+        m = self.model.compiled
+        std = np.ascontiguousarray(std, dtype=np.float64)
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        if std.shape != (m.nu,) or table.ndim != 2 or table.shape[1] != m.nu or table.shape[0] < 1:
+            raise ConfigError("feedback noise must have shapes std [nu], table [nsteps, nu]")
+        _check(load_library().mjb_set_feedback_noise(self.ptr, std.ctypes.data, table.ctypes.data, int(table.shape[0]), int(env_stride)))
+
+    def feedback_ctrl(self, step: int = 0) -> None:
+        """Evaluate the feedback law for every environment on the device (fp32: MFMA GEMM) and write ``ctrl`` there."""
+        _check(load_library().mjb_feedback_ctrl(self.ptr, int(step)))
 
     def make_obs_spec(self, flags: int, site_ids=(), body_ids=(), geom_ids=(), subtree_ids=()) -> ObsSpecHandle:
         return ObsSpecHandle(self, flags, site_ids, body_ids, geom_ids, subtree_ids)

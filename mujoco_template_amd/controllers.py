@@ -107,16 +107,26 @@ class RandomCtrlController:
 
 @dataclass
 class LinearFeedbackController:
-    """``ctrl = clip(ctrl0 - K [q (-) q_goal ; qvel - qvel_goal])`` — the LQR feedback law of the reference's
-    examples (``examples/humanoid/controllers/lqr.py:147-170``, ``examples/drone2/main.py:400-471``), evaluated
-    inside the fused rollout kernel (``device_ctrl_mode = "feedback"``).  ``__call__`` is the same law on the host."""
+    """``ctrl = clip(ctrl0 - K [q (-) q_goal ; qvel - qvel_goal] + std o P[step])`` — the LQR feedback law of the reference's
+    examples (``examples/humanoid/controllers/lqr.py:147-170``, ``examples/drone2/main.py:400-471``), including its optional
+    pre-drawn ctrl noise (``lqr.py:160-165``).  Three evaluations of the same law:
+
+    * inside the fused rollout kernel (``device_ctrl_mode = "feedback"``, ``Env.rollout`` / ``run_passive_headless``);
+    * ``__call__`` in a host-driven loop: ONE batched kernel for all environments (``mjb_feedback_ctrl``: ``K dx`` as an MFMA GEMM
+      ``[batch, 2nv] x [2nv, nu]`` in fp32) writes ``ctrl`` on the device — no per-environment Python;
+    * :meth:`host_law`: numpy on the host mirrors (what the tests compare the two device forms with).
+    """
 
     K: np.ndarray = None            # [nu, 2 nv]
     ctrl0: np.ndarray = None        # [nu]
     qpos_goal: np.ndarray = None    # [nq]
     qvel_goal: np.ndarray | None = None
+    ctrl_noise_std: np.ndarray | None = None     # [nu]
+    perturbations: np.ndarray | None = None      # [nsteps, nu]: the reference's pre-drawn table, indexed by the step (mod nsteps)
+    env_stride: int = 0                          # phase offset of the table per environment (0: every environment sees the same noise)
     capabilities: ControllerCapabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
     device_ctrl_mode: str = "feedback"
+    step_count: int = field(default=0)
 
     def prepare(self, model: Any, data: Any) -> None:
         if model.nu == 0:
@@ -127,18 +137,42 @@ class LinearFeedbackController:
         self.qvel_goal = np.zeros(model.nv) if self.qvel_goal is None else np.asarray(self.qvel_goal, dtype=float)
         if self.K.shape != (model.nu, 2 * model.nv) or self.ctrl0.shape != (model.nu,) or self.qpos_goal.shape != (model.nq,):
             raise ConfigError("LinearFeedbackController: K must be [nu, 2nv], ctrl0 [nu], qpos_goal [nq]")
+        if (self.ctrl_noise_std is None) != (self.perturbations is None):
+            raise ConfigError("LinearFeedbackController: ctrl_noise_std and perturbations go together")
+        self.step_count = 0
+        self._uploaded = None
+
+    def upload(self, sim: Any) -> None:
+        """Gains (and noise) to the device object, once per (controller, sim) pair."""
+        if getattr(self, "_uploaded", None) is not sim:
+            sim.set_feedback(self.K, self.ctrl0, self.qpos_goal, self.qvel_goal)
+            sim.set_feedback_noise(self.ctrl_noise_std, self.perturbations, self.env_stride)
+            self._uploaded = sim
 
     def __call__(self, model: Any, data: Any, t: float) -> None:
+        sim = data.sim
+        data.push_host_edits()
+        self.upload(sim)
+        sim.feedback_ctrl(self.step_count)
+        self.step_count += 1
+        data.mark_device_newer()                 # ctrl now lives on the device: the mirrors refresh on the next read / step
+
+    def host_law(self, model: Any, data: Any, step: int | None = None) -> np.ndarray:
+        """The same law with numpy on the host mirrors; returns ctrl [batch, nu] (does not write it)."""
         from . import mj
 
-        rows, qpos, qvel = _ctrl_rows(data), np.atleast_2d(data.qpos), np.atleast_2d(data.qvel)
+        qpos, qvel = np.atleast_2d(np.asarray(data.qpos, dtype=float)), np.atleast_2d(np.asarray(data.qvel, dtype=float))
+        B = qpos.shape[0]
         lo = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 0], -np.inf)
         hi = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 1], np.inf)
-        dq = np.zeros(model.nv)
-        for e in range(rows.shape[0]):
-            mj.mj_differentiatePos(model, dq, 1.0, self.qpos_goal, qpos[e])
-            dx = np.concatenate([dq, qvel[e] - self.qvel_goal])
-            rows[e] = np.clip(self.ctrl0 - self.K @ dx, lo, hi)
+        dq = np.zeros((B, model.nv))
+        mj.mj_differentiatePos(model, dq, 1.0, np.ascontiguousarray(np.tile(self.qpos_goal, (B, 1))), np.ascontiguousarray(qpos))
+        u = self.ctrl0 - np.concatenate([dq, qvel - self.qvel_goal], axis=1) @ self.K.T
+        if self.perturbations is not None:
+            step = self.step_count if step is None else step
+            idx = (step + np.arange(B) * self.env_stride) % len(self.perturbations)
+            u = u + np.asarray(self.ctrl_noise_std) * np.asarray(self.perturbations)[idx]
+        return np.clip(u, lo, hi)
 
 
 __all__ = ["ZeroController", "PositionTargetDemo", "RandomCtrlController", "LinearFeedbackController", "philox_uniform"]

@@ -2,8 +2,8 @@
 #include "mjb_kernels.hpp"
 namespace mjb {
 template <>
-hipError_t launch_fd<double, float>(int G, const DevModel<double>* m, const Lay* Ldev, const Lay& L, const DevData<float>& d, int ncol, double eps, double* y, int* valid, hipStream_t stream) {
-  MJB_DISPATCH_G(G, return (launch_fd_g<double, float, GG>(m, Ldev, L, d, ncol, eps, y, valid, stream)));
+hipError_t launch_fd<double, float>(int G, const DevModel<double>* m, const Lay* Ldev, const Lay& L, const DevData<float>& d, int ncol, int nv, int nu, int chunk, double eps, double* y, int* valid, hipStream_t stream) {
+  MJB_DISPATCH_G(G, return (launch_fd_g<double, float, GG>(m, Ldev, L, d, ncol, nv, nu, chunk, eps, y, valid, stream)));
   return hipErrorInvalidValue;
 }
 template <>

@@ -93,6 +93,10 @@ struct mjbData {
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   int* fd_valid = nullptr;
+  // standalone feedback law (mjb_feedback_ctrl): optional noise (std [nu], table [nsteps, nu]) in both precisions, dx scratch for float64
+  float *fb_noise_f[2] = {nullptr, nullptr};
+  double *fb_noise_d[2] = {nullptr, nullptr}, *fb_dx = nullptr;
+  int fb_nsteps = 0, fb_env_stride = 0;
   // host mirror (mjb_host_view): ONE pinned float64 block  qpos | qvel | ctrl | qacc | qacc_warmstart | time , each [batch, n],
   // and its device staging twin; filled by one pack kernel + one D2H per mjb_sync_to_host
   double *mirror_host = nullptr, *mirror_dev = nullptr;
@@ -577,6 +581,11 @@ int mjb_rollout(mjbData* d, int nstep, int ctrl_mode, unsigned seed, unsigned st
   if (ctrl_mode == 3) {
     if (d->dtype == MJB_F32) { a.fb_K = d->fbf[0]; a.fb_u0 = d->fbf[1]; a.fb_q0 = d->fbf[2]; a.fb_v0 = d->fbf[3]; }
     else { a.fb_K = d->fbd[0]; a.fb_u0 = d->fbd[1]; a.fb_q0 = d->fbd[2]; a.fb_v0 = d->fbd[3]; }
+    if (d->fb_nsteps > 0) {
+      a.fb_nsteps = d->fb_nsteps; a.fb_env_stride = d->fb_env_stride;
+      a.fb_noise_std = d->dtype == MJB_F32 ? (const void*)d->fb_noise_f[0] : (const void*)d->fb_noise_d[0];
+      a.fb_noise_tab = d->dtype == MJB_F32 ? (const void*)d->fb_noise_f[1] : (const void*)d->fb_noise_d[1];
+    }
   }
   ObsSpecDev obs; std::memset(&obs, 0, sizeof(obs));
   if (spec && obs_out_dev && obs_every > 0) { obs = spec->dev; a.obs_every = obs_every; }
@@ -600,6 +609,55 @@ int mjb_set_feedback(mjbData* d, const double* K, const double* u0, const double
       HIPCHK(hipMemcpy(d->fbf[k], vf.data(), n[k] * sizeof(float), hipMemcpyHostToDevice));
     }
   }
+  return MJB_OK;
+}
+
+
+int mjb_set_feedback_noise(mjbData* d, const double* noise_std, const double* noise_table, int nsteps, int env_stride) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  d->fb_env_stride = env_stride;
+  if (!noise_std || !noise_table || nsteps < 1) { d->fb_nsteps = 0; return MJB_OK; }      // switch the noise term off
+  const HostModel& h = d->model->h;
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  const size_t n[2] = {(size_t)h.nu, (size_t)nsteps * h.nu};
+  const double* src[2] = {noise_std, noise_table};
+  for (int k = 0; k < 2; k++) {
+    double* pd = nullptr; float* pf = nullptr;
+    if (dev_alloc(d, &pd, n[k]) || dev_alloc(d, &pf, n[k])) return fail(MJB_ERR_DEVICE, "device allocation of the feedback noise failed");
+    std::vector<float> vf(src[k], src[k] + n[k]);
+    HIPCHK(hipMemcpy(pd, src[k], n[k] * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pf, vf.data(), n[k] * sizeof(float), hipMemcpyHostToDevice));
+    d->fb_noise_d[k] = pd; d->fb_noise_f[k] = pf;             // earlier tables stay owned by the data object until it is freed
+  }
+  d->fb_nsteps = nsteps;
+  return MJB_OK;
+}
+
+int mjb_feedback_ctrl(mjbData* d, int step) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (!d->fbd[0]) return fail(MJB_ERR_ARG, "mjb_feedback_ctrl needs mjb_set_feedback() first");
+  const HostModel& h = d->model->h;
+  if (h.nu == 0) return MJB_OK;
+  HIPCHK(hipSetDevice(d->device));
+  { int rc0 = refresh_options(d); if (rc0 != MJB_OK) return rc0; }
+  FeedbackArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.nsteps = d->fb_nsteps; a.step = step; a.env_stride = d->fb_env_stride;
+  if (d->dtype == MJB_F32) {
+    a.K = d->fbf[0]; a.u0 = d->fbf[1]; a.q0 = d->fbf[2]; a.v0 = d->fbf[3];
+    if (d->fb_nsteps > 0) { a.noise_std = d->fb_noise_f[0]; a.noise_tab = d->fb_noise_f[1]; }
+    const int kpad = (2 * h.nv + 1) & ~1;
+    const size_t shmem = (size_t)32 * kpad * sizeof(float);
+    if (shmem > 64 * 1024) return fail(MJB_ERR_ARG, "mjb_feedback_ctrl: 2 nv too large for the LDS tile");
+    hipLaunchKernelGGL(k_feedback_mfma<0>, dim3((unsigned)((d->batch + 31) / 32)), dim3(64), shmem, d->stream, (const DevModel<float>*)d->mf_dev, d->df, a);
+  } else {
+    a.K = d->fbd[0]; a.u0 = d->fbd[1]; a.q0 = d->fbd[2]; a.v0 = d->fbd[3];
+    if (d->fb_nsteps > 0) { a.noise_std = d->fb_noise_d[0]; a.noise_tab = d->fb_noise_d[1]; }
+    if (!d->fb_dx && dev_alloc(d, &d->fb_dx, (size_t)d->batch * 2 * h.nv)) return fail(MJB_ERR_DEVICE, "device allocation of the feedback scratch failed");
+    hipLaunchKernelGGL(k_feedback_simple<double>, dim3((unsigned)d->batch), dim3(64), 0, d->stream, (const DevModel<double>*)d->md_dev, d->dd, a, d->fb_dx);
+  }
+  HIPCHK(hipGetLastError());
   return MJB_OK;
 }
 
@@ -667,8 +725,23 @@ int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, doub
         dev_alloc(d, &d->fd_A, B * nx * nx) || dev_alloc(d, &d->fd_B, B * nx * (h.nu > 0 ? h.nu : 1)))
       return fail(MJB_ERR_DEVICE, "device allocation of FD scratch failed");
   }
-  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, ncol, eps, d->fd_y, d->fd_valid, d->stream)
-                                     : launch_fd<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, ncol, eps, d->fd_y, d->fd_valid, d->stream);
+  // columns per job (k_fd shares the stages a chunk of columns cannot change): as many as keep >= ~4 jobs per residency slot,
+  // at most 8; a single environment keeps one column per job (latency over throughput)
+  int chunk = 8;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || ncu < 1) ncu = 256;
+    const size_t per_wg = (size_t)(64 / d->G_fd) * (size_t)d->Ld.bytes;
+    size_t wg_per_cu = per_wg ? (size_t)160 * 1024 / per_wg : 8;
+    if (wg_per_cu > 32) wg_per_cu = 32;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    const long slots = (long)wg_per_cu * ncu * (64 / d->G_fd);
+    const long want = (long)B * ncol / (4 * slots);
+    if (const char* e = std::getenv("MJB_FD_CHUNK")) chunk = std::atoi(e);        // experiments (scripts/gpu_fd_timing.py)
+    else chunk = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
+  }
+  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream)
+                                     : launch_fd<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream);
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("fd launch: ") + hipGetErrorString(e));
   long nthreads = (long)B * nin;
   hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, (const DevModel<double>*)d->md_dev, d->batch, ncol, centered, eps,

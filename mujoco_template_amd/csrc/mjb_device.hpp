@@ -173,7 +173,19 @@ MJB_DEV float t_rsqrt(float a) { float y = __builtin_amdgcn_rsqf(a); return y * 
 #else
 MJB_DEV float t_rsqrt(float a) { return 1.0f / sqrtf(a); }
 #endif
+#ifndef MJB_HOST_EMU
+// v_rsq_f64 (about 2^-26 relative) + two Newton steps on y <- y (1.5 - 0.5 a y^2): full double precision in ~10 instructions
+// instead of the library sqrt + division on the pivot chain of the float64 factorisations (finite differences, validation path)
+MJB_DEV double t_rsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  const double ha = 0.5 * a;
+  y = y * (1.5 - ha * y * y);
+  y = y * (1.5 - ha * y * y);
+  return y;
+}
+#else
 MJB_DEV double t_rsqrt(double a) { return 1.0 / sqrt(a); }
+#endif
 MJB_DEV float t_sin(float a) { return sinf(a); }
 MJB_DEV double t_sin(double a) { return sin(a); }
 MJB_DEV float t_cos(float a) { return cosf(a); }
@@ -2160,18 +2172,30 @@ template <typename T, typename TS, int G> MJB_DEV void sensors(const Ctx<T>& c, 
 // ---------------------------------------------------------------------------
 // mj_forward for one environment (state in LDS)
 // ---------------------------------------------------------------------------
-template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
+// The three stages of mj_forward, separately callable: mjd_transitionFD skips the stages a perturbed column cannot change
+// (MuJoCo's mj_stepSkip: ctrl columns keep the position and velocity stages, velocity columns the position stage).
+template <typename T, int G> MJB_DEV void forward_position(Ctx<T>& c) {
   MJB_STAMP(c, PH_OTHER);
   kinematics<T, G>(c); MJB_STAMP(c, PH_KIN);
   com_pos<T, G>(c); MJB_STAMP(c, PH_COM);
   collision<T, G>(c); MJB_STAMP(c, PH_COLL);
   crb_factor<T, G>(c); MJB_STAMP(c, PH_CRB);
+}
+// constraint rows (their reference acceleration depends on qvel) + bias / passive forces
+template <typename T, int G> MJB_DEV void forward_velocity(Ctx<T>& c) {
   make_constraint<T, G>(c); MJB_STAMP(c, PH_CONS);
   vel_bias_passive<T, G>(c); MJB_STAMP(c, PH_VEL);
-  if (c.skip_dynamics) return;                              // mj_inverse: position + velocity stages only (inverse_dynamics() follows)
+}
+template <typename T, int G> MJB_DEV void forward_acceleration(Ctx<T>& c) {
   actuation_acceleration<T, G>(c); MJB_STAMP(c, PH_ACT);
   solve_constraints<T, G>(c); MJB_STAMP(c, PH_SOLVE);
   if (c.mp->nsensor > 0) { sensors<T, T, G>(c, c.w + c.lp->sens); gsync<G>(); }   // like mj_forward: sensors see the pre-integration state
+}
+template <typename T, int G> MJB_DEV void forward(Ctx<T>& c) {
+  forward_position<T, G>(c);
+  forward_velocity<T, G>(c);
+  if (c.skip_dynamics) return;                              // mj_inverse: position + velocity stages only (inverse_dynamics() follows)
+  forward_acceleration<T, G>(c);
 }
 
 // A16 position integration for the joints of one environment (lanes over joints)
@@ -2260,7 +2284,7 @@ template <typename T, int G> MJB_DEV void random_ctrl(ModelRef<T> m, T* ctrl, un
 
 // Linear state-feedback controller evaluated on the device (the LQR law of the reference's examples,
 // examples/humanoid/controllers/lqr.py:147-170): ctrl = clip(u0 - K dx), dx = [q (-) q0 ; qvel - v0] in tangent space.
-template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, const StepArgs& a) {
+template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, const StepArgs& a, unsigned env, unsigned step) {
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nu = m.nu;
   auto K = (const T MJB_CONST*)a.fb_K; auto u0 = (const T MJB_CONST*)a.fb_u0;
   auto q0 = (const T MJB_CONST*)a.fb_q0; auto v0 = (const T MJB_CONST*)a.fb_v0;
@@ -2279,6 +2303,10 @@ template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, const StepArg
   for (int act = lane; act < nu; act += G) {
     T u = u0[act];
     for (int k = 0; k < 2 * nv; k++) u -= K[act * 2 * nv + k] * dx[k];
+    if (a.fb_nsteps > 0) {
+      const long idx = ((long)step + (long)env * a.fb_env_stride) % a.fb_nsteps;
+      u += ((const T MJB_CONST*)a.fb_noise_std)[act] * ((const T MJB_CONST*)a.fb_noise_tab)[idx * nu + act];
+    }
     if (m.actuator_ctrllimited[act]) u = t_min(t_max(u, m.actuator_ctrlrange[2 * act]), m.actuator_ctrlrange[2 * act + 1]);
     ctrl[act] = u;
   }
@@ -2397,7 +2425,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
       if (a.ctrl_mode == CTRL_RANDOM) {
         random_ctrl<T, G>(m, w + L.ctrl, a.seed, a.env0 + (unsigned)env, a.step0 + (unsigned)s, (T)a.ctrl_scale, lane);
         gsync<G>();
-      } else if (a.ctrl_mode == CTRL_FEEDBACK) feedback_ctrl<T, G>(c, a);
+      } else if (a.ctrl_mode == CTRL_FEEDBACK) feedback_ctrl<T, G>(c, a, a.env0 + (unsigned)env, a.step0 + (unsigned)s);
     }
     bool retried = false;
     for (int st = 0; st < nstage; st++) {

@@ -140,6 +140,9 @@ struct StepArgs {
   int obs_every;         // >0: write flat obs every k steps into obs_out[(step/k), env, dim]
   // CTRL_FEEDBACK: ctrl = clip(u0 - K [differentiatePos(q0, qpos); qvel - v0]) with K [nu, 2nv] row-major (dtype of the arithmetic)
   const void *fb_K, *fb_u0, *fb_q0, *fb_v0;
+  // optional ctrl noise of that law (reference lqr.py:160-165): + std[a] * table[(step + env * stride) mod nsteps][a] before the clip
+  const void *fb_noise_std, *fb_noise_tab;
+  int fb_nsteps, fb_env_stride;
 };
 
 }  // namespace mjb

@@ -164,7 +164,7 @@ class Env:
         data, sim, ctl = self.data, self.data.sim, self.controller
         data.push_host_edits()
         if mode == CTRL_FEEDBACK:
-            sim.set_feedback(ctl.K, ctl.ctrl0, ctl.qpos_goal, ctl.qvel_goal)
+            ctl.upload(sim)                                      # gains + optional ctrl noise, once per (controller, sim)
         spec, ring_ptr = None, 0
         if obs_every > 0:
             import torch

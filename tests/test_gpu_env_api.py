@@ -515,3 +515,43 @@ def test_fd_fallback_is_float64_batched_and_matches_native_away_from_zero():
             chain = Ak @ chain
             h64.step()
         assert np.abs(A3 - chain).max() <= 2e-4 * max(1.0, np.abs(chain).max())
+
+
+@pytest.mark.parametrize("name,B", [("humanoid", 100), ("drone2", 33), ("cartpole", 64)])
+def test_batched_feedback_gemm_kernel_matches_the_host_law(name, B):
+    """mjb_feedback_ctrl (SURVEY §8(f) rank 2 as specified: K dx as a batched [B, 2nv] x [2nv, nu] GEMM on MFMA in fp32, plain
+    float64 otherwise) incl. the reference law's pre-drawn ctrl noise (lqr.py:160-165) against the numpy law on the host mirrors;
+    batches that are not a multiple of the 32-environment tile, nu from 1 to 21."""
+    rng = np.random.default_rng(11)
+    for dtype, tol in (("float32", 2e-5), ("float64", 1e-12)):
+        h = mt.ModelHandle.from_xml_path(MODELS[name], batch=B, dtype=dtype)
+        m, d = h.model, h.data
+        K = rng.normal(size=(m.nu, 2 * m.nv)) * 0.2
+        u0 = rng.uniform(-0.2, 0.2, size=m.nu) + (3.0 if name == "drone2" else 0.0)
+        ctl = mt.LinearFeedbackController(K=K, ctrl0=u0, qpos_goal=np.array(m.qpos0), qvel_goal=rng.normal(size=m.nv) * 0.01,
+                                          ctrl_noise_std=rng.uniform(0.0, 0.05, size=m.nu), perturbations=rng.normal(size=(7, m.nu)), env_stride=3)
+        ctl.prepare(m, d)
+        dq = rng.normal(size=(B, m.nv)) * 0.1
+        q = np.tile(np.array(m.qpos0), (B, 1))
+        mj.mj_integratePos(m, q, dq, 1.0)                      # quaternion-aware offsets (humanoid / drone root)
+        d.qpos[:] = q
+        d.qvel[:] = rng.normal(size=(B, m.nv)) * 0.3
+        for step in (0, 5):
+            ctl.step_count = step
+            want = ctl.host_law(m, d, step)                    # from the float64 mirrors of the (possibly fp32) device state
+            ctl(m, d, 0.0)
+            got = np.array(d.ctrl)
+            assert got.shape == (B, m.nu)
+            assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (name, dtype, step)
+        lim = np.asarray(m.actuator_ctrllimited, dtype=bool)
+        assert (got[:, lim] <= m.actuator_ctrlrange[lim, 1] + 1e-12).all() and (got[:, lim] >= m.actuator_ctrlrange[lim, 0] - 1e-12).all()
+        # the law inside the fused rollout uses the same noise table (step = the rollout's step counter)
+        env = mt.Env.from_xml_path(MODELS[name], controller=mt.LinearFeedbackController(K=K, ctrl0=u0, qpos_goal=np.array(m.qpos0), qvel_goal=ctl.qvel_goal,
+                                   ctrl_noise_std=ctl.ctrl_noise_std, perturbations=ctl.perturbations, env_stride=3), batch=B, dtype=dtype)
+        env.data.qpos[:] = q
+        env.data.qvel[:] = np.array(d.qvel)
+        ctl.step_count = 0
+        ctl.qpos_goal = np.array(m.qpos0)
+        first = ctl.host_law(m, env.data, 0)
+        env.rollout(1)
+        assert np.abs(np.array(env.data.ctrl) - first).max() <= (5e-5 if dtype == "float32" else 1e-12) * max(1.0, np.abs(first).max())

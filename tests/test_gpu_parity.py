@@ -367,13 +367,20 @@ def test_full_size_humanoid_properties(world):
     rng = cm.jnt_range[1:]                                                     # hinge limits hold up to soft-constraint slack
     assert (q[:, 7:] > rng[:, 0] - 0.35).all() and (q[:, 7:] < rng[:, 1] + 0.35).all()
     assert np.array_equal(q, runs[1][0]) and np.array_equal(v, runs[1][1])     # bitwise deterministic
-    # a sample of environments against the oracle for the first 60 steps: free-running fp32 through 8 foot contacts, i.e.
-    # rounding differences already amplified by the contact dynamics (measured 0.5e-3 .. 1.1e-3 depending on the FMA
-    # contraction rule of the build; the tight fp32 check is the teacher-forced single-step test above)
-    sim = BatchSim(dm, 8, dtype="float32")
-    sim.rollout(60, CTRL_RANDOM, seed=0)
-    qo, _ = mjo.rollout_batch(om, 8, 60, seed=0, nthreads=4)
-    assert np.abs(sim.get("qpos") - qo).max() < 3e-3
+    # A sample of environments against the oracle, free-running fp32 through the foot contacts (BASELINE: qpos drift <= 1e-4).
+    # Measured curve and attribution: profiles/r02_humanoid_drift.log, r02_humanoid_phase_errors.log (256 envs, full-scale random
+    # ctrl): max 3.6e-5 @ 20 steps; median 2.5e-5 / 90th pct 1.0e-4 @ 60 steps; median 1.0e-4 @ 100.  Per step fp32 injects ~1.4e-7
+    # in qpos and ~5e-3 in qacc (M and the bias force are only known to fp32: M^-1 amplifies that by cond(M) ~ 4e3), which the
+    # contact dynamics then grow exactly as they grow a 1e-7 perturbation of the float64 run (the "f64+1e-7" column of the log).
+    S = 64
+    sim = BatchSim(dm, S, dtype="float32")
+    sim.rollout(20, CTRL_RANDOM, seed=0)
+    qo, _ = mjo.rollout_batch(om, S, 20, seed=0, nthreads=8)
+    assert np.abs(sim.get("qpos") - qo).max() < 1e-4                         # the whole sample inside BASELINE's bound at 20 steps
+    sim.rollout(40, CTRL_RANDOM, seed=0, step0=20)
+    qo, _ = mjo.rollout_batch(om, S, 60, seed=0, nthreads=8)
+    err = np.abs(sim.get("qpos") - qo).max(axis=1)
+    assert np.median(err) < 1e-4 and np.quantile(err, 0.9) < 5e-4, (np.median(err), np.quantile(err, 0.9), err.max())
 
 
 def test_device_feedback_controller_matches_host_law(world):
