@@ -109,6 +109,7 @@ def main() -> None:
     ap.add_argument("--no-host-loop", action="store_true", help="skip the host-driven Env.passive measurement (Python controller in the loop)")
     ap.add_argument("--nefcmax", type=int, default=0)
     ap.add_argument("--nconmax", type=int, default=0)
+    ap.add_argument("--tolerance", type=float, default=0.0, help="solver tolerance (model.opt.tolerance); 0 = the model's own (experiments)")
     ap.add_argument("--no-specialize", action="store_true", help="use the generic step kernel instead of the per-model specialised one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-process path (observations staged through the host)")
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -153,12 +154,13 @@ def main() -> None:
     env = Env.from_xml_path(os.path.join(ROOT, xml), obs_spec=ObservationSpec(as_dict=False),
                             controller=RandomCtrlController(seed=0, scale=scale), batch=count, dtype="float32", device=device,
                             env0=env0, nefcmax=args.nefcmax, nconmax=args.nconmax, specialize=False if args.no_specialize else None)
+    if args.tolerance > 0:
+        env.model.opt.tolerance = args.tolerance
     sim = env.data.sim
     sim.use_torch_stream()
     obs_dim = env.extractor.obs_dim
     nq, nv, nu = env.model.nq, env.model.nv, env.model.nu
-    # steps fused per launch: --chunk, but never fewer than 5 timed launches (a short --steps run is then not one single launch)
-    chunk = max(1, min(args.chunk, -(-args.steps // 5)))
+    chunk = max(1, min(args.chunk, args.steps))               # steps fused per launch
 
     def run(nsteps: int, events=None) -> None:
         done = 0
@@ -191,6 +193,12 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    in_region = len(events)
+    # the roofline's launch duration is an average over >= 5 launches: when the timed region was fewer (a short --steps run is ONE
+    # fused launch), more launches of the same length follow it here - they count for `roofline` only, never for `value`
+    while len(events) < 5:
+        run(events[0][2], events)
+    torch.cuda.synchronize()
     counters = env.data.counters()
     kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     steps_per_launch = [n for _, _, n in events]
@@ -246,7 +254,7 @@ def main() -> None:
                        "nefcmax": sim.nefcmax, "nconmax": sim.nconmax, "specialized_kernel": bool(sim.specialized)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("mjb_k_step_spec (k_step<float,float,%d> with the model's sizes/offsets folded in)" if sim.specialized else "mjb::k_step<float,float,%d>") % sim.lanes,
-                         "traffic_source": traffic_source, "launch_steps": avg_steps, "launches_timed": len(kernel_ms),
+                         "traffic_source": traffic_source, "launch_steps": avg_steps, "launches_timed": len(kernel_ms), "launches_in_timed_region": in_region,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_env_step": bytes_step, "obs_bytes_per_env": bytes_obs,
                          "note": "fused step is VALU/LDS-latency bound by construction (SURVEY.md §8d); see DESIGN.md for VALU/LDS counters"},
             "solver": {"mean_nefc_last_step": float(counters["nefc"].mean()), "max_nefc_last_step": int(counters["nefc"].max()),

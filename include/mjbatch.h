@@ -156,6 +156,9 @@ int mjb_obs_gather(mjbData* d, const mjbObsSpec* s, void* out_dev /* [batch, dim
 /* ---- mjd_transitionFD (reference linearization.py:16-35): float64 on device.
  * A_host [batch, 2nv, 2nv], B_host [batch, 2nv, nu], row-major ---- */
 int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, double* B_host);
+/* the same without the final host copy: pointers to the library's PINNED result blocks (same layouts), valid until the next
+ * mjb_transition_fd* call on this data object — at humanoid batch 512 the two blocks are 16.5 MB */
+int mjb_transition_fd_pinned(mjbData* d, double eps, int centered, const double** A_pinned, const double** B_pinned);
 
 /* ---- mj_jacSite / mj_jacBody / mj_jacBodyCom / mj_jacSubtreeCom (reference jacobians.py:44-79).
  * kinds[i]: 0 site, 1 body, 2 bodycom, 3 subtreecom.  jacp/jacr host [batch, nreq, 3, nv] float64 (jacr may be NULL) ---- */

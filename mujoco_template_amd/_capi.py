@@ -88,6 +88,8 @@ def load_library() -> ctypes.CDLL:
     L.mjb_obs_dim.argtypes = [vp]
     L.mjb_obs_gather.argtypes = [vp, vp, vp]
     L.mjb_transition_fd.argtypes = [vp, cd, ci, vp, vp]
+    L.mjb_transition_fd_pinned.argtypes = [vp, cd, ci, ctypes.POINTER(ctypes.POINTER(cd)), ctypes.POINTER(ctypes.POINTER(cd))]
+    L.mjb_transition_fd_pinned.restype = ci
     L.mjb_jac.argtypes = [vp, ci, vp, vp, vp, vp]
     L.mjb_profile_get.argtypes = [vp, vp]
     L.mjb_profile_get.restype = ci
@@ -558,13 +560,15 @@ class BatchSim:
     def obs_gather(self, spec: ObsSpecHandle, out_ptr: int) -> None:
         _check(load_library().mjb_obs_gather(self.ptr, spec.ptr, ctypes.c_void_p(out_ptr)))
 
-    def transition_fd(self, eps: float = 1e-6, centered: bool = True) -> tuple[np.ndarray, np.ndarray]:
+    def transition_fd(self, eps: float = 1e-6, centered: bool = True, *, copy: bool = True) -> tuple[np.ndarray, np.ndarray]:
+        """(A [batch, 2nv, 2nv], B [batch, 2nv, nu]).  ``copy=False`` returns views of the library's pinned result blocks (no
+        16 MB host copy at humanoid batch 512), valid until the next ``transition_fd`` on this object."""
         m = self.model.compiled
-        A = np.zeros((self.batch, 2 * m.nv, 2 * m.nv))
-        B = np.zeros((self.batch, 2 * m.nv, max(m.nu, 1)))
-        Bv = np.zeros((self.batch, 2 * m.nv, m.nu))
-        _check(load_library().mjb_transition_fd(self.ptr, float(eps), int(bool(centered)), A.ctypes.data, (Bv if m.nu else B).ctypes.data))
-        return A, Bv
+        pa, pb = ctypes.POINTER(ctypes.c_double)(), ctypes.POINTER(ctypes.c_double)()
+        _check(load_library().mjb_transition_fd_pinned(self.ptr, float(eps), int(bool(centered)), ctypes.byref(pa), ctypes.byref(pb)))
+        A = np.ctypeslib.as_array(pa, shape=(self.batch, 2 * m.nv, 2 * m.nv))
+        Bv = np.ctypeslib.as_array(pb, shape=(self.batch, 2 * m.nv, m.nu)) if m.nu else np.zeros((self.batch, 2 * m.nv, 0))
+        return (A.copy(), Bv.copy()) if copy else (A, Bv)
 
     def jac(self, kinds: Sequence[int], ids: Sequence[int]) -> tuple[np.ndarray, np.ndarray]:
         m = self.model.compiled

@@ -92,6 +92,7 @@ struct mjbData {
   hipFunction_t spec_fn = nullptr;
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
+  double *fd_A_host = nullptr, *fd_B_host = nullptr;          // pinned: the (A, B) blocks leave the device in one async copy each
   int* fd_valid = nullptr;
   // standalone feedback law (mjb_feedback_ctrl): optional noise (std [nu], table [nsteps, nu]) in both precisions, dx scratch for float64
   float *fb_noise_f[2] = {nullptr, nullptr};
@@ -413,6 +414,8 @@ void mjb_data_free(mjbData* d) {
   (void)hipSetDevice(d->device);
   for (void* p : d->owned) (void)hipFree(p);
   if (d->mirror_host) (void)hipHostFree(d->mirror_host);
+  if (d->fd_A_host) (void)hipHostFree(d->fd_A_host);
+  if (d->fd_B_host) (void)hipHostFree(d->fd_B_host);
   d->alloc.release();
   delete d;
 }
@@ -712,8 +715,8 @@ int mjb_obs_gather(mjbData* d, const mjbObsSpec* s, void* out_dev) {
   return MJB_OK;
 }
 
-int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, double* B_host) {
-  if (!d || !A_host || !B_host) return fail(MJB_ERR_ARG, "NULL argument");
+static int transition_fd_impl(mjbData* d, double eps, int centered) {
+  if (!d) return fail(MJB_ERR_ARG, "NULL argument");
   if (!(eps > 0)) return fail(MJB_ERR_ARG, "eps must be > 0");
   const HostModel& h = d->model->h;
   HIPCHK(hipSetDevice(d->device));
@@ -724,6 +727,8 @@ int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, doub
     if (dev_alloc(d, &d->fd_y, B * ncol * (h.nq + h.nv)) || dev_alloc(d, &d->fd_valid, B * ncol) ||
         dev_alloc(d, &d->fd_A, B * nx * nx) || dev_alloc(d, &d->fd_B, B * nx * (h.nu > 0 ? h.nu : 1)))
       return fail(MJB_ERR_DEVICE, "device allocation of FD scratch failed");
+    HIPCHK(hipHostMalloc((void**)&d->fd_A_host, B * nx * nx * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&d->fd_B_host, B * nx * (h.nu > 0 ? h.nu : 1) * sizeof(double), hipHostMallocDefault));
   }
   // columns per job (k_fd shares the stages a chunk of columns cannot change): as many as keep >= ~4 jobs per residency slot,
   // at most 8; a single environment keeps one column per job (latency over throughput)
@@ -747,11 +752,32 @@ int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, doub
   hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, (const DevModel<double>*)d->md_dev, d->batch, ncol, centered, eps,
                      (const double*)d->fd_y, (const int*)d->fd_valid, d->fd_A, d->fd_B);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(d->fd_A_host, d->fd_A, B * nx * nx * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  if (h.nu > 0) HIPCHK(hipMemcpyAsync(d->fd_B_host, d->fd_B, B * nx * h.nu * sizeof(double), hipMemcpyDeviceToHost, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
-  HIPCHK(hipMemcpy(A_host, d->fd_A, B * nx * nx * sizeof(double), hipMemcpyDeviceToHost));
-  if (h.nu > 0) HIPCHK(hipMemcpy(B_host, d->fd_B, B * nx * h.nu * sizeof(double), hipMemcpyDeviceToHost));
   return MJB_OK;
 }
+
+int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, double* B_host) {
+  if (!d || !A_host || !B_host) return fail(MJB_ERR_ARG, "NULL argument");
+  int rc = transition_fd_impl(d, eps, centered);
+  if (rc != MJB_OK) return rc;
+  const HostModel& h = d->model->h;
+  const size_t B = (size_t)d->batch, nx = 2 * (size_t)h.nv;
+  std::memcpy(A_host, d->fd_A_host, B * nx * nx * sizeof(double));
+  if (h.nu > 0) std::memcpy(B_host, d->fd_B_host, B * nx * h.nu * sizeof(double));
+  return MJB_OK;
+}
+
+int mjb_transition_fd_pinned(mjbData* d, double eps, int centered, const double** A_pinned, const double** B_pinned) {
+  if (!d || !A_pinned || !B_pinned) return fail(MJB_ERR_ARG, "NULL argument");
+  int rc = transition_fd_impl(d, eps, centered);
+  if (rc != MJB_OK) return rc;
+  *A_pinned = d->fd_A_host; *B_pinned = d->fd_B_host;
+  return MJB_OK;
+}
+
+
 
 int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp_host, double* jacr_host) {
   if (!d || !kinds || !ids || !jacp_host || nreq < 1) return fail(MJB_ERR_ARG, "bad argument");

@@ -414,7 +414,7 @@ def mjd_transitionFD(model: MjModel, data: MjData, eps: float, centered: bool, A
         raise TypeError("mjd_transitionFD takes 8 positional arguments")
     _check(model, data)
     data.push_host_edits()
-    Ab, Bb = data._sim.transition_fd(float(eps), bool(centered))
+    Ab, Bb = data._sim.transition_fd(float(eps), bool(centered), copy=False)       # pinned views: copied once, into the caller's arrays
     if A is not None:
         A[...] = Ab[0] if A.ndim == 2 else Ab
     if B is not None and model.nu > 0:

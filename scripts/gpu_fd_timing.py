@@ -12,7 +12,11 @@ for name, B, scale in (("cartpole", 512, 0.01), ("cartpole", 4096, 0.01), ("dron
     sim.transition_fd(1e-6, True)
     t = time.time(); n = 5
     for _ in range(n):
-        A, Bm = sim.transition_fd(1e-6, True)
+        A, Bm = sim.transition_fd(1e-6, True, copy=False)          # the call the Python front makes (mjd_transitionFD copies once, into the caller's arrays)
     dt = (time.time() - t) / n
+    t = time.time()
+    for _ in range(n):
+        sim.transition_fd(1e-6, True, copy=True)
+    dtc = (time.time() - t) / n
     ncol = 1 + 2 * (2 * cm.nv + cm.nu)
-    print(f"{name:14s} B={B:5d}: transition_fd {dt*1e3:8.2f} ms per call = {B/dt:.3e} linearisations/s = {B*ncol/dt:.3e} perturbed env-steps/s (float64, {ncol} columns), A {A.shape} B {Bm.shape}", flush=True)
+    print(f"{name:14s} B={B:5d}: transition_fd {dt*1e3:8.2f} ms per call = {B/dt:.3e} linearisations/s = {B*ncol/dt:.3e} perturbed env-steps/s (float64, {ncol} columns; {dtc*1e3:.2f} ms with a host copy of A/B), A {A.shape} B {Bm.shape}", flush=True)

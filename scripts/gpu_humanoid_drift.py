@@ -22,6 +22,8 @@ scales = [float(s) for s in sys.argv[2:]] or [1.0, 0.1, 0.0]
 cm = compile_xml_path(os.path.join(ROOT, "models/humanoid.xml"))
 om = mjo.OracleModel(cm)
 dm = DeviceModel(cm)
+if os.environ.get("MJB_TOL"):                                          # experiment: solver tolerance of the fp32 / float64 kernels (the oracle keeps 1e-8)
+    dm.set_solver(cm.iterations, float(os.environ["MJB_TOL"]))
 rng = np.random.default_rng(0)
 HORIZONS = (1, 10, 20, 40, 60, 100, 150, 200, 300, 400, 500, 600, 800, 1000)
 
