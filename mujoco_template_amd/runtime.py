@@ -69,19 +69,23 @@ def run_passive_headless(env: "Env", *, duration: float | None = None, max_steps
     _validate(duration, max_steps)
     active_hooks = _normalize_hooks(hooks)
     if not active_hooks and env.can_fuse():   # nothing observes the intermediate StepResults
-        # fused path: number of steps is known up front (time advances by exactly one timestep per step)
+        # fused path: chunks of steps per launch.  With a duration stop the clocks are re-read after every chunk: normally time
+        # advances by exactly one timestep per step, but an in-kernel bad-state reset restarts that environment's clock
+        # (mj_checkPos/Vel/Acc -> mj_resetData), and the per-step loop would keep stepping until EVERY clock has reached the duration.
         dt = float(env.model.opt.timestep)
-        limit = max_steps
-        if duration is not None:
-            t0 = float(np.min(np.asarray(env.data.time)))
-            need = max(1, int(np.ceil((duration - t0) / dt - 1e-9)))
-            limit = need if limit is None else min(limit, need)
-        if limit is not None:
-            done = 0
-            while done < limit:
-                n = min(chunk, limit - done)
-                env.rollout(n)
-                done += n
+        done = 0
+        while max_steps is None or done < max_steps:
+            n = chunk if max_steps is None else min(chunk, max_steps - done)
+            if duration is not None:
+                t_min = float(np.min(np.asarray(env.data.time)))
+                if done > 0 and t_min >= duration:
+                    break
+                n = min(n, max(1, int(np.ceil((duration - t_min) / dt - 1e-9))))     # never step past the slowest clock's target
+            elif max_steps is None:
+                break                                  # no stop condition at all: like the generator, fall through to one plain step
+            env.rollout(n)
+            done += n
+        if done > 0:
             return done
     steps = 0
     for _ in iterate_passive(env, duration=duration, max_steps=max_steps, hooks=active_hooks, return_obs=return_obs):

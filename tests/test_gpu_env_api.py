@@ -555,3 +555,25 @@ def test_batched_feedback_gemm_kernel_matches_the_host_law(name, B):
         first = ctl.host_law(m, env.data, 0)
         env.rollout(1)
         assert np.abs(np.array(env.data.ctrl) - first).max() <= (5e-5 if dtype == "float32" else 1e-12) * max(1.0, np.abs(first).max())
+
+
+def test_fused_headless_run_waits_for_a_clock_restarted_by_the_bad_state_guard():
+    """run_passive_headless's fused path used to fix its step count up front; an in-kernel bad-state reset
+    (mj_checkVel -> mj_resetData: that environment's clock restarts at 0) must extend a `duration` run exactly as the per-step
+    loop would (runtime.py:631-663 stops when EVERY clock has reached the duration)."""
+    def make():
+        env = mt.Env.from_xml_path(MODELS["cartpole"], controller=mt.ZeroController(), batch=3, dtype="float32")
+        env.data.time = 0.03
+        env.data.qvel[1, 0] = 1e12                                   # environment 1 trips the guard at its first step
+        return env
+
+    a = make()
+    with pytest.warns(RuntimeWarning, match="bad-state"):
+        n = runtime.run_passive_headless(a, duration=0.08, chunk=4)
+        times = np.array(a.data.time)
+    dt = float(a.model.opt.timestep)                                  # 0.01: the healthy clocks need 5 steps, the restarted one 8
+    assert n == 8 and times == pytest.approx([0.03 + 8 * dt, 8 * dt, 0.03 + 8 * dt])
+    assert a.data.counters()["warn_badqvel"].tolist() == [0, 1, 0]
+    b = make()                                                        # the per-step loop (a hook forces it) agrees
+    with pytest.warns(RuntimeWarning, match="bad-state"):
+        assert runtime.run_passive_headless(b, duration=0.08, hooks=lambda r: None) == 8
