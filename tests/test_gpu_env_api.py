@@ -255,7 +255,11 @@ def test_env_passive_duration_and_keyframes():
     env = mt.Env.from_xml_path(MODELS["drone2"], keyframe="hover")
     assert env.data.qpos == pytest.approx([0, 0, 0.3, 1, 0, 0, 0]) and env.data.ctrl == pytest.approx([3.2495625] * 4)
     n = runtime.run_passive_headless(env, duration=0.1)
-    assert n == 10 and env.data.time == pytest.approx(0.1)
+    # ten steps of 0.01 accumulate to 0.09999999999999999 < 0.1 in float64 (MuJoCo's `time += timestep` does the same), so the
+    # reference's stop test `data.time >= duration` (runtime.py:658-663) lets an ELEVENTH step through; fused and per-step paths agree
+    assert n == 11 and env.data.time == pytest.approx(0.11)
+    again = mt.Env.from_xml_path(MODELS["drone2"], keyframe="hover")
+    assert runtime.run_passive_headless(again, duration=0.1, hooks=lambda r: None) == 11
     assert env.data.qpos == pytest.approx([0, 0, 0.3, 1, 0, 0, 0], abs=1e-5)    # hover is a fixed point (K1)
     with pytest.raises(mt.NameLookupError):
         env.reset("nope")
