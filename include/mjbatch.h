@@ -153,6 +153,13 @@ void mjb_obs_spec_free(mjbObsSpec* s);
 int mjb_obs_dim(const mjbObsSpec* s);
 int mjb_obs_gather(mjbData* d, const mjbObsSpec* s, void* out_dev /* [batch, dim], dtype of the data */);
 
+/* the ONE collective of the path: all-gather of the flat observation block over RCCL / xGMI for a host that owns
+ * an ncclComm_t (one process per GPU): send_dev [count_per_rank] -> recv_dev [nranks * count_per_rank], dtype MJB_F32 / MJB_F64, on
+ * hip_stream.  The Python front uses torch.distributed's all_gather_into_tensor instead (distributed.all_gather_obs); this entry
+ * point is the same ncclAllGather for a non-Python host.  The library does not link RCCL: it resolves ncclAllGather from the RCCL
+ * already in the process, else from librccl.so.1. */
+int mjb_allgather_obs(void* nccl_comm, const void* send_dev, void* recv_dev, long count_per_rank, int dtype, void* hip_stream);
+
 /* ---- mjd_transitionFD (reference linearization.py:16-35): float64 on device.
  * A_host [batch, 2nv, 2nv], B_host [batch, 2nv, nu], row-major ---- */
 int mjb_transition_fd(mjbData* d, double eps, int centered, double* A_host, double* B_host);

@@ -3,6 +3,8 @@
 // kernels of mjb_kernels.hpp on the caller's HIP stream.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1024,6 +1026,32 @@ int mjb_step_host(mjbData* d, int nstep, int field_mask) {
   if (nstep > 0 && (rc = launch(d, make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0), none, nullptr, false)) != MJB_OK) return rc;
   if (nstep == 0 && (rc = launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, false)) != MJB_OK) return rc;   // mj_forward
   return mirror_pull(d);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// observation all-gather over RCCL for a host that owns an ncclComm_t (SURVEY.md §8(b) "allgather_obs", §8(e)): the ONE
+// collective of the path.  The library does not link RCCL: the symbol is taken from the RCCL the process already loaded
+// (torch's bundled one, or the host's), else from librccl.so.1.
+// ---------------------------------------------------------------------------------------------------------------------
+int mjb_allgather_obs(void* nccl_comm, const void* send_dev, void* recv_dev, long count_per_rank, int dtype, void* hip_stream) {
+  if (!nccl_comm || !send_dev || !recv_dev || count_per_rank < 0) return fail(MJB_ERR_ARG, "mjb_allgather_obs: NULL / negative argument");
+  if (dtype != MJB_F32 && dtype != MJB_F64) return fail(MJB_ERR_ARG, "dtype must be MJB_F32 or MJB_F64");
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_fn fn = nullptr;
+  if (!fn) {
+    fn = (allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+    if (!fn) {
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+      if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (h) fn = (allgather_fn)dlsym(h, "ncclAllGather");
+    }
+    if (!fn) return fail(MJB_ERR_DEVICE, "ncclAllGather not found: no RCCL in this process and librccl.so.1 is not loadable");
+  }
+  const int nccl_dtype = dtype == MJB_F32 ? 7 /* ncclFloat32 */ : 8 /* ncclFloat64 */;
+  const int rc = fn(send_dev, recv_dev, (size_t)count_per_rank, nccl_dtype, nccl_comm, (hipStream_t)hip_stream);
+  if (rc != 0) return fail(MJB_ERR_DEVICE, "ncclAllGather failed with ncclResult " + std::to_string(rc));
+  return MJB_OK;
 }
 
 int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [24] per-phase cycle sums; zero unless built with -DMJB_PROFILE */) {

@@ -1,6 +1,7 @@
 """The reference's unit/integration assertions (reference tests/test_mujoco_template.py:74-588: shapes,
 key sets, identity / shares_memory, call counts, ordering) re-targeted at the batched ``Env``, plus
 the batched fast paths (fused rollout, device observation gather).  Needs a GPU (no CPU fallback)."""
+import os
 import warnings
 
 import numpy as np
@@ -581,3 +582,48 @@ def test_fused_headless_run_waits_for_a_clock_restarted_by_the_bad_state_guard()
     b = make()                                                        # the per-step loop (a hook forces it) agrees
     with pytest.warns(RuntimeWarning, match="bad-state"):
         assert runtime.run_passive_headless(b, duration=0.08, hooks=lambda r: None) == 8
+
+
+def test_c_abi_allgather_obs_runs_ncclallgather_on_a_one_rank_communicator():
+    """mjb_allgather_obs (SURVEY §8(b) export list): the path's one collective for a host that owns an ncclComm_t.  Exercised here
+    with a one-rank RCCL communicator created through ctypes on the RCCL torch loaded (the multi-rank case is torch.distributed's
+    all_gather_into_tensor in the Python front; two ranks cannot share the one GPU of this box)."""
+    import ctypes
+
+    import torch
+
+    from mujoco_template_amd._capi import load_library
+
+    L = load_library()
+    L.mjb_allgather_obs.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+    L.mjb_allgather_obs.restype = ctypes.c_int
+    assert L.mjb_allgather_obs(None, None, None, 4, 0, None) == -1                      # argument check, no RCCL call
+    rccl = None
+    for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1"):
+        try:
+            rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no loadable librccl")
+    class UniqueId(ctypes.Structure):                                                   # ncclUniqueId: 128 opaque bytes, passed BY VALUE
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        send = torch.arange(6 * 55, device="cuda", dtype=torch.float32).reshape(6, 55) * 0.5
+        recv = torch.zeros_like(send)
+        stream = torch.cuda.current_stream().cuda_stream
+        assert L.mjb_allgather_obs(comm, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()), send.numel(), 0, ctypes.c_void_p(stream)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
