@@ -341,3 +341,95 @@ def test_parallel_capsules_give_two_contacts():
     od.qpos[7 + 3:7 + 7] = [np.cos(5e-4), 0, np.sin(5e-4), 0]    # rotation about y
     od.forward()
     assert od.counters()["ncon"] == 1
+
+
+def test_bias_and_mass_matrix_match_euler_lagrange_on_a_fixed_base_humanoid(models):
+    """An anchor that does not go through the oracle's RNE / CRB recursions, nor through anything MuJoCo-specific: Lagrangian mechanics.
+    For a tree of hinges  M(q) qdd + c(q, qd) = tau  with  c_i = sum_jk (dM_ij/dq_k - 1/2 dM_jk/dq_i) qd_j qd_k + dV/dq_i.
+    M(q) comes from the Jacobian form (sum of m Jp^T Jp + Jr^T I Jr: mjcf.mass_matrix_numpy, plain kinematics), V(q) = -sum m g.x_com,
+    the derivatives by central differences.  The humanoid with its free joint removed (21 hinges, every limb, both tendon-coupled
+    legs) at random configurations and velocities: the oracle's qM and qfrc_bias must reproduce M and c."""
+    from mujoco_template_amd import mjcf
+
+    xml = open(models["humanoid"]).read().replace('<freejoint name="root"/>', "")
+    a, b = xml.index("<keyframe>"), xml.index("</keyframe>") + len("</keyframe>")
+    xml = xml[:a] + xml[b:]                                          # the keyframes are written for nq = 28
+    cm = mjcf.compile_xml_string(xml)
+    assert cm.nv == 21 and cm.nq == 21
+    od = mjo.OracleData(mjo.OracleModel(cm))
+    g = np.array(cm.gravity)
+
+    def M_of(q):
+        return mjcf.mass_matrix_numpy(cm, mjcf.kinematics_numpy(cm, q))
+
+    def V_of(q):
+        kin = mjcf.kinematics_numpy(cm, q)
+        return -float(sum(cm.body_mass[bb] * g @ kin["xipos"][bb] for bb in range(1, cm.nbody)))
+
+    rng = np.random.default_rng(3)
+    eps = 1e-6
+    for _ in range(3):
+        q = np.array(cm.qpos0) + rng.uniform(-0.4, 0.4, size=cm.nq)
+        v = rng.normal(size=cm.nv) * 2.0
+        dM = np.zeros((cm.nv, cm.nv, cm.nv))                         # dM[k] = dM / dq_k
+        dV = np.zeros(cm.nv)
+        for k in range(cm.nv):
+            e = np.zeros(cm.nv); e[k] = eps
+            dM[k] = (M_of(q + e) - M_of(q - e)) / (2 * eps)
+            dV[k] = (V_of(q + e) - V_of(q - e)) / (2 * eps)
+        Mdot_v = np.einsum("kij,k,j->i", dM, v, v)                    # (dM/dt) v
+        half = 0.5 * np.einsum("ijk,j,k->i", dM, v, v)               # 1/2 d(v^T M v)/dq_i
+        c = Mdot_v - half + dV
+        od.qpos[:] = q; od.qvel[:] = v; od.ctrl[:] = 0
+        od.forward()
+        M = M_of(q)
+        assert np.abs(od.qM.reshape(cm.nv, cm.nv) - M).max() < 1e-12 * max(1.0, np.abs(M).max())
+        assert np.abs(od.qfrc_bias - c).max() < 2e-6 * max(1.0, np.abs(c).max()), np.abs(od.qfrc_bias - c).max()
+        # passive forces of this model are joint springs and dampers only: closed form
+        want = -cm.dof_damping * v - cm.jnt_stiffness * (q - cm.qpos_spring)
+        assert od.qfrc_passive == pytest.approx(want, abs=1e-12)
+
+
+def test_free_floating_humanoid_momentum_balance(models):
+    """Newton-Euler for the WHOLE articulated body, independent of how qacc was computed (CRB, RNE, the solver, actuation, joint
+    springs / dampers / limits are all internal forces): with the humanoid in the air the only external force is gravity, so
+        d/dt sum m_b v_b = M g,      d/dt sum (m_b x_b x v_b + I_b w_b) = sum x_b x m_b g
+    Momenta from plain kinematics (Jacobian form); the time derivative by advancing (q, qd) a virtual 1e-6 s with the oracle's qacc.
+    Covers what the fixed-base Euler-Lagrange check cannot: the free joint's Coriolis terms and the quaternion velocity convention."""
+    from mujoco_template_amd import mjcf
+
+    cm = mjcf.compile_xml_path(models["humanoid"])
+    om = mjo.OracleModel(cm)
+    od = mjo.OracleData(om)
+    g = np.array(cm.gravity)
+
+    def momenta(q, v):
+        kin = mjcf.kinematics_numpy(cm, q)
+        P, Lm = np.zeros(3), np.zeros(3)
+        for b in range(1, cm.nbody):
+            if cm.body_mass[b] <= 0:
+                continue
+            jp, jr = mjcf.jac_point_numpy(cm, kin, b, kin["xipos"][b])
+            Iw = kin["ximat"][b] @ np.diag(cm.body_inertia[b]) @ kin["ximat"][b].T
+            vb, wb = jp @ v, jr @ v
+            P += cm.body_mass[b] * vb
+            Lm += cm.body_mass[b] * np.cross(kin["xipos"][b], vb) + Iw @ wb
+        torque_g = sum(np.cross(kin["xipos"][b], cm.body_mass[b] * g) for b in range(1, cm.nbody))
+        return P, Lm, torque_g
+
+    rng = np.random.default_rng(8)
+    mtot = float(cm.body_mass.sum())
+    for _ in range(3):
+        dq = rng.normal(size=cm.nv) * 0.15
+        dq[:3] = [0.3, -0.2, 2.0]                                   # two metres up: no floor contact
+        q = od.integrate_pos(cm.qpos0, dq, 1.0)
+        v = rng.normal(size=cm.nv) * 1.5
+        od.qpos[:] = q; od.qvel[:] = v; od.ctrl[:] = rng.uniform(-1, 1, size=cm.nu)
+        od.forward()
+        floor = cm.name2id(mjcf.OBJ_GEOM, "floor")
+        assert floor not in od.contacts()["geom1"].tolist()          # self-contacts may occur: they are internal forces too
+        h = 1e-6
+        P0, L0, tg = momenta(q, v)
+        P1, L1, _ = momenta(od.integrate_pos(q, v, h), v + h * od.qacc)
+        assert (P1 - P0) / h == pytest.approx(mtot * g, abs=2e-4 * mtot * 9.81)
+        assert (L1 - L0) / h == pytest.approx(tg, abs=2e-4 * max(1.0, np.abs(tg).max(), np.abs(L0).max() / 0.01))
