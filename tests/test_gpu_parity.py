@@ -115,6 +115,32 @@ def test_parallel_capsules_two_contacts(dtype):
     assert np.abs(sim.get("qpos")[0] - od.qpos).max() <= (1e-10 if dtype == "float64" else 2e-6)
 
 
+def test_sliding_box_four_corner_contacts_with_friction():
+    """plane-box contacts (4 corners x 4 pyramid rows) under sliding friction: a box thrown along the floor at 2 m/s with some spin.
+    float64 kernels follow the oracle through the stick-slip hopping (tests/test_oracle_anchors.py::test_coulomb_friction...) to
+    rounding; fp32 after 20 steps to 1e-4 (contact-rich from step 0)."""
+    xml = """<mujoco><option timestep="0.002"/><worldbody><geom type="plane" size="0 0 1" friction="0.5"/>
+      <body pos="0 0 0.1"><freejoint/><geom type="box" size="0.1 0.08 0.1" density="1000" friction="0.5"/></body></worldbody></mujoco>"""
+    cm = mjcf.compile_xml_string(xml)
+    om, dm = mjo.OracleModel(cm), DeviceModel(cm)
+    B = 4
+    v0 = np.zeros((B, 6)); v0[:, 0] = 2.0; v0[:, 1] = np.linspace(-0.5, 0.5, B); v0[:, 5] = np.linspace(0.0, 3.0, B)
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    for e, od in enumerate(ods):
+        od.qvel[:] = v0[e]
+    for dtype, steps, tol in (("float64", 300, 1e-9), ("float32", 20, 1e-4)):
+        for e, od in enumerate(ods):
+            od.reset(); od.qvel[:] = v0[e]
+            for _ in range(steps):
+                od.step()
+        sim = BatchSim(dm, B, dtype=dtype)
+        sim.set("qvel", v0)
+        sim.step(steps)
+        assert np.abs(sim.get("qpos") - np.stack([od.qpos for od in ods])).max() <= tol, dtype
+        assert sim.counters()["efc_dropped"].sum() == 0
+    assert np.stack([od.qvel for od in ods])[:, 0].max() < 2.0 - 0.8 * 0.5 * 9.81 * 0.04         # 20 steps: friction took >= 80 % of mu g t off the speed
+
+
 @pytest.mark.parametrize("name,steps", [("pendulum", 200), ("cartpole", 200), ("drone2", 100), ("humanoid", 150)])
 def test_float64_free_running_matches_oracle(world, name, steps):
     """Same kernels in double: rounding-level agreement over whole trajectories, contacts included."""
