@@ -102,6 +102,8 @@ def load_library() -> ctypes.CDLL:
     L.mjb_model_id2name.restype = ctypes.c_char_p
     L.mjb_model_field.argtypes = [vp, ctypes.c_char_p, pvp, pcl, pci]
     L.mjb_model_field_at.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), pvp, pcl, pci]
+    L.mjb_model_load_xml.argtypes = [ctypes.c_char_p, pvp]
+    L.mjb_model_load_xml_string.argtypes = [ctypes.c_char_p, ctypes.c_char_p, pvp]
     L.mjb_model_save.argtypes = [vp, ctypes.c_char_p]
     L.mjb_model_load.argtypes = [ctypes.c_char_p, pvp]
     L.mjb_integrate_pos.argtypes = [vp, ci, vp, vp, cd]
@@ -114,7 +116,7 @@ def load_library() -> ctypes.CDLL:
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
                  "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get", "mjb_model_field", "mjb_model_field_at", "mjb_model_save",
-                 "mjb_model_load", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
+                 "mjb_model_load", "mjb_model_load_xml", "mjb_model_load_xml_string", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
                  "mjb_step_host"):
         getattr(L, name).restype = ci
     _LIB = L
@@ -321,6 +323,19 @@ class DeviceModel:
 
     def save(self, path: str) -> None:
         _check(load_library().mjb_model_save(self.ptr, os.fsencode(path)))
+
+    # -- MjModel.from_xml_path / from_xml_string (reference model.py:22-27): the native MJCF compiler -----
+    @classmethod
+    def load_xml(cls, path: str) -> "DeviceModel":
+        ptr = ctypes.c_void_p()
+        _check(load_library().mjb_model_load_xml(os.fsencode(os.path.abspath(path)), ctypes.byref(ptr)))
+        return cls(None, _ptr=ptr)
+
+    @classmethod
+    def load_xml_string(cls, xml_text: str, base_dir: str = ".") -> "DeviceModel":
+        ptr = ctypes.c_void_p()
+        _check(load_library().mjb_model_load_xml_string(xml_text.encode(), os.fsencode(os.path.abspath(base_dir)), ctypes.byref(ptr)))
+        return cls(None, _ptr=ptr)
 
     def fields(self) -> dict[str, np.ndarray]:
         """Every field of the model table as a numpy copy (``mjb_model_field_at``)."""

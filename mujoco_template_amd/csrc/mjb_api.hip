@@ -331,6 +331,8 @@ int copy_out(mjbData* d, const ArrayInfo& ai, double* host_out) {
 extern "C" {
 
 const char* mjb_last_error(void) { return g_err.c_str(); }
+// for the other translation units of the library (mjb_mjcf.cpp): set the error string, return the code
+int mjb_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 int mjb_device_count(void) {
   int n = 0;

@@ -106,7 +106,7 @@ class MjModel:
 
     def __init__(self, compiled: CompiledModel):
         self._c = compiled
-        self._dm: DeviceModel | None = None
+        self._dm: DeviceModel | None = compiled.__dict__.get("_device_model")      # the handle the native compiler returned, if any
         self.opt = _Option(self)
 
     # construction ---------------------------------------------------------------

@@ -298,3 +298,57 @@ def test_unsupported_mjcf_attributes_are_rejected_loudly():
     ok = ok.replace("<worldbody>", '<visual><global offwidth="800"/></visual><option><flag gravity="enable"/></option><worldbody><light pos="0 0 3"/>')
     ok = ok.replace('<geom name="torso_geom"', '<geom rgba="1 0 0 1" name="torso_geom"')
     assert mjcf.compile_xml_string(ok).nv == 1
+
+
+def test_native_compiler_matches_the_python_restatement(models):
+    """The product compiler is native (csrc/mjb_mjcf.cpp behind mjb_model_load_xml); tests/pymjcf.py is an independent pure-Python
+    restatement of it.  Every field of every model must agree (1e-12 relative; principal frames through the inertia tensors, the
+    eigenvector signs of a 3x3 eigen-decomposition being a free choice) — the one check of the compiler that does not pass through
+    both the oracle and the HIP path."""
+    from tests import pymjcf
+    from tests.conftest import CAPSULES_XML
+
+    cases = [(k, dict(path=v)) for k, v in models.items()] + [("base", dict(text=BASE_XML)), ("capsules", dict(text=CAPSULES_XML))]
+    for name, kw in cases:
+        a = pymjcf.compile_xml_path(kw["path"]) if "path" in kw else pymjcf.compile_xml_string(kw["text"])
+        b = mjcf.compile_xml_path(kw["path"]) if "path" in kw else mjcf.compile_xml_string(kw["text"])
+        for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nwrap", "nsensor", "nsensordata", "nkey", "npair", "nexclude",
+                  "integrator", "iterations", "ls_iterations", "disableactuator", "name"):
+            assert getattr(a, k) == getattr(b, k), (name, k)
+        for k in ("timestep", "density", "viscosity", "impratio", "tolerance", "meaninertia"):
+            assert getattr(a, k) == pytest.approx(getattr(b, k), rel=1e-13), (name, k)
+        assert np.array_equal(a.gravity, b.gravity) and a.names == b.names and set(a.arrays) == set(b.arrays), name
+        for k in a.arrays:
+            x, y = np.asarray(a.arrays[k], dtype=float), np.asarray(b.arrays[k], dtype=float)
+            assert x.shape == y.shape, (name, k)
+            if k in ("body_iquat", "body_inertia") or x.size == 0:
+                continue
+            assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(x).max()), (name, k)
+        for bb in range(a.nbody):
+            ia = mjcf.quat_to_mat(a.body_iquat[bb]) @ np.diag(a.body_inertia[bb]) @ mjcf.quat_to_mat(a.body_iquat[bb]).T
+            ib = mjcf.quat_to_mat(b.body_iquat[bb]) @ np.diag(b.body_inertia[bb]) @ mjcf.quat_to_mat(b.body_iquat[bb]).T
+            assert np.abs(ia - ib).max() <= 1e-12 * max(1e-30, np.abs(ia).max()), (name, bb)
+            assert np.sort(a.body_inertia[bb]) == pytest.approx(np.sort(b.body_inertia[bb]), rel=1e-12, abs=1e-18)
+
+
+def test_model_load_xml_through_the_c_abi(models, tmp_path):
+    """mjb_model_load_xml / mjb_model_load_xml_string (SURVEY §8(b) "model_load_xml"): a host in any language compiles MJCF through the
+    C ABI; <include> resolves against the file's directory; errors come back as MJB_ERR_MODEL with the compiler's message."""
+    import ctypes
+
+    from mujoco_template_amd._capi import load_library
+
+    L = load_library()
+    m = ctypes.c_void_p()
+    assert L.mjb_model_load_xml(models["drone2"].encode(), ctypes.byref(m)) == 0          # scene.xml includes x2.xml
+    p, n, dt = ctypes.c_void_p(), ctypes.c_long(), ctypes.c_int()
+    assert L.mjb_model_field(m, b"nq", ctypes.byref(p), ctypes.byref(n), ctypes.byref(dt)) == 0
+    assert ctypes.cast(p, ctypes.POINTER(ctypes.c_int))[0] == 7 and L.mjb_model_name2id(m, 6, b"imu") == 0
+    L.mjb_model_free(m)
+    bad = tmp_path / "bad.xml"
+    bad.write_text("<mujoco><equality/></mujoco>")
+    assert L.mjb_model_load_xml(str(bad).encode(), ctypes.byref(m)) == -2 and b"equality" in L.mjb_last_error()
+    assert L.mjb_model_load_xml(b"/nonexistent.xml", ctypes.byref(m)) == -2 and b"not found" in L.mjb_last_error()
+    assert L.mjb_model_load_xml_string(b"<mujoco><worldbody><body><joint/></body>", b".", ctypes.byref(m)) == -2 and b"XML parse error" in L.mjb_last_error()
+    assert L.mjb_model_load_xml_string(b"<mujoco><worldbody><body><joint/></body></worldbody></mujoco>", b".", ctypes.byref(m)) == -2
+    assert b"zero mass" in L.mjb_last_error()
