@@ -193,6 +193,33 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # companion figure for N > 1 (all ranks take part): the SAME per-GPU work as the N = 1 run (per-GPU batch = the global batch of
+    # BASELINE's config), i.e. the weak-scaling point next to the strong-scaling headline.  Never `value`.
+    weak_companion = None
+    if distributed and not args.weak:
+        wenv = Env.from_xml_path(os.path.join(ROOT, xml), obs_spec=ObservationSpec(as_dict=False),
+                                 controller=RandomCtrlController(seed=0, scale=scale), batch=args.global_batch, dtype="float32", device=device,
+                                 env0=rank * args.global_batch, nefcmax=args.nefcmax, nconmax=args.nconmax, specialize=False if args.no_specialize else None)
+        wenv.data.sim.use_torch_stream()
+        wcounts = [args.global_batch] * ws
+
+        def wrun(nsteps: int) -> None:
+            done = 0
+            while done < nsteps:
+                n = min(chunk, nsteps - done)
+                all_gather_obs(wenv.rollout(n, obs_every=n), counts=wcounts)
+                done += n
+
+        wrun(args.warmup)
+        barrier()
+        tw = time.perf_counter()
+        wrun(args.steps)
+        barrier()
+        welapsed = torch.tensor([time.perf_counter() - tw], device=f"cuda:{device}", dtype=torch.float64)
+        dist.all_reduce(welapsed, op=dist.ReduceOp.MAX)
+        weak_companion = {"value": args.global_batch * ws * args.steps / float(welapsed.item()), "unit": "env-steps/s", "scaling": "weak",
+                          "per_gpu_batch": args.global_batch, "global_batch": args.global_batch * ws, "ms_per_step": float(welapsed.item()) * 1e3 / args.steps}
+        del wenv
     in_region = len(events)
     # the roofline's launch duration is an average over >= 5 launches: when the timed region was fewer (a short --steps run is ONE
     # fused launch), more launches of the same length follow it here - they count for `roofline` only, never for `value`
@@ -262,6 +289,8 @@ def main() -> None:
                        "dropped_contacts": int(counters["con_dropped"].sum()), "dropped_rows": int(counters["efc_dropped"].sum()),
                        "bad_state_resets": int(counters["warn_badqpos"].sum() + counters["warn_badqvel"].sum() + counters["warn_badqacc"].sum())},
         }
+        if weak_companion is not None:
+            out["weak_scaling_companion"] = weak_companion
         if ws == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, xml), scale)
         if ws == 1 and not args.no_host_loop:
