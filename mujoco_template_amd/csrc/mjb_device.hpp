@@ -29,7 +29,33 @@
 #define MJB_DEVM __device__ __forceinline__
 #endif
 
+// Wave-level intrinsics behind macros: the device build expands them to the gfx950 builtins (unchanged code), the test-only host
+// emulation (mjb_hostemu.hpp) to collectives of its lane threads - so the CPU suite runs the MFMA / readlane solver code itself.
+#ifdef MJB_HOST_EMU
+#define MJB_MFMA(a, b, acc) emu_mfma((a), (b), (acc))
+#define MJB_BALLOT(p) emu_ballot(p)
+#define MJB_RSQF(x) (1.0f / sqrtf(x))
+#define MJB_RCPF(x) (1.0f / (x))
+#define MJB_MEMTIME() 0ull
+#define MJB_OPAQUE1(a) ((void)0)
+#define MJB_OPAQUE2(a, b) ((void)0)
+#define MJB_OPAQUE9(a, b, c, d, e, f, g, h, i) ((void)0)
+#else
+#define MJB_MFMA(a, b, acc) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
+#define MJB_BALLOT(p) __ballot(p)
+#define MJB_RSQF(x) __builtin_amdgcn_rsqf(x)
+#define MJB_RCPF(x) __builtin_amdgcn_rcpf(x)
+#define MJB_MEMTIME() __builtin_amdgcn_s_memtime()
+#define MJB_OPAQUE1(a) asm volatile("" : "+v"(a))
+#define MJB_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define MJB_OPAQUE9(a, b, c, d, e, f, g, h, i) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i))
+#endif
+
 namespace mjb {
+
+#ifndef MJB_HOST_EMU
+typedef float mjb_f16v __attribute__((ext_vector_type(16)));     // the 32x32 fp32 MFMA accumulator: 16 registers per lane
+#endif
 
 // ---------------------------------------------------------------------------
 // group primitives
@@ -514,7 +540,6 @@ template <typename T> struct Ctx {
 // VGPRs; a column step is one v_readlane + one FMA per trailing column — no LDS, no sync, no branches.
 // Entries above the diagonal hold garbage that is never read.  Modes as tile_factor.
 // ---------------------------------------------------------------------------
-#ifndef MJB_HOST_EMU
 template <typename T, typename MRef>
 MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T* dw, int nefc, int mode, int n, int lane, T* x) {
   T a[32];
@@ -568,7 +593,6 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
     gsync<64>();
   }
 }
-#endif
 
 // ---------------------------------------------------------------------------
 // MFMA Cholesky (fp32, G == 64, n <= 32): the symmetric 32x32 matrix lives in the accumulator layout of
@@ -582,7 +606,6 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
 #define MJB_SWEEP_EXCLUDE 1      // factor_W mode that keeps the Cholesky path (1 = Hessian); -1: sweep everywhere
 #endif
 #ifndef MJB_HOST_EMU
-typedef float mjb_f16v __attribute__((ext_vector_type(16)));
 MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane half, column-aligned, in all 64 lanes
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(half == 0 ? p[0] : p[1]);
@@ -597,6 +620,7 @@ MJB_DEV double half_sum(double v) {
   auto pl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
   return __hiloint2double((int)ph[0], (int)pl[0]) + __hiloint2double((int)ph[1], (int)pl[1]);
 }
+#endif
 // Backward substitution L^T x = y, 8 rows at a time.  rs holds x pre-scaled by the lane's own 1/L_cc, so the serial chain
 // per row is one v_readlane + one FMA; the next block's rows are loaded while the current chain runs.
 MJB_DEV void mfma_back_load8(float (&dst)[8], const float* Wc, int blk, int n) {
@@ -610,7 +634,7 @@ MJB_DEV void mfma_back_load8(float (&dst)[8], const float* Wc, int blk, int n) {
 }
 MJB_DEV void mfma_back_chain8(float (&lrow)[8], int blk, int n, int c_, float myinv, float& rs) {
   int c = c_;
-  asm volatile("" : "+v"(c), "+v"(lrow[0]), "+v"(lrow[1]), "+v"(lrow[2]), "+v"(lrow[3]), "+v"(lrow[4]), "+v"(lrow[5]), "+v"(lrow[6]), "+v"(lrow[7]));
+  MJB_OPAQUE9(c, lrow[0], lrow[1], lrow[2], lrow[3], lrow[4], lrow[5], lrow[6], lrow[7]);
 #pragma unroll
   for (int t = 0; t < 8; t++) { const int j = 8 * blk + t; lrow[t] = (c < j && j < n) ? lrow[t] * myinv : 0.0f; }
 #pragma unroll
@@ -648,7 +672,7 @@ MJB_DEV void mfma_solve32(const float* W, const float* dinv, float* x, int n, in
     if (blk > top) continue;
     float lrow[8];
     int c = c_;
-    asm volatile("" : "+v"(c));
+    MJB_OPAQUE1(c);
 #pragma unroll
     for (int t = 0; t < 8; t++) lrow[t] = Wr[8 * blk + t];      // L[c][j]; j >= c reads past the row: masked below
 #pragma unroll
@@ -664,7 +688,7 @@ MJB_DEV void mfma_solve32(const float* W, const float* dinv, float* x, int n, in
 template <typename MRef>
 MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
   const int h = lane >> 5, c_ = lane & 31;
-  unsigned long long tq0 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tq0 = pf ? MJB_MEMTIME() : 0;
   mjb_f16v acc;
   {
     // acc[4q+t] of lane (h, c) = A[8q+4h+t][c] = A[c][8q+4h+t] (symmetric): every lane reads along its own row of M,
@@ -687,7 +711,7 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
       for (int base = 0; base < nefc; base += 64) {
         const int rix = base + lane;
         const float dl = rix < nefc ? dw[rix] : 0.0f;
-        unsigned long long act = __ballot(dl != 0.0f);
+        unsigned long long act = MJB_BALLOT(dl != 0.0f);
         float jcur = 0.0f, dcur = 0.0f;
         bool have = false;
         while (act) {
@@ -698,10 +722,10 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
           int rr = h == 0 ? ra : rb;
           float jn = J[(base + rr) * n + cm];
           float dn = h == 0 ? dA : dB;
-          if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+          if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
           jcur = c < n ? jn : 0.0f; dcur = dn; have = true;
         }
-        if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+        if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
       }
     }
   }
@@ -710,20 +734,20 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
   const int wrow = tri_at(c_, 0), cvalid = (h == 0 && c_ < n) ? 0 : -1;
   float* const wrowp = W + wrow;
   float* const dumpp = dinv + n;                              // one spare word behind dinv swallows the masked stores
-  unsigned long long tq1 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tq1 = pf ? MJB_MEMTIME() : 0;
 #pragma unroll
   for (int jb = 0; jb < 16; jb++) {
     const int j0 = 2 * jb, j1 = j0 + 1, hj = (j0 >> 2) & 1, ij = 4 * (j0 >> 3) + (j0 & 3);
     if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
     int c = c_;
-    asm volatile("" : "+v"(c));                               // keep the per-column lane compares in the loop (cheaper than spilled masks)
+    MJB_OPAQUE1(c);                               // keep the per-column lane compares in the loop (cheaper than spilled masks)
     // columns j0, j1 of the trailing matrix, one entry per lane; the 2x2 pivot block [a b; b d] is eliminated in scalars
     // so that the serial chain per panel is rsq -> fma -> rsq
     float v0 = half_bcast(acc[ij], hj), v1r = half_bcast(acc[ij + 1], hj);
     float a = __builtin_fmaxf(rdlane_f(v0, j0), Num<float>::minval()), b = rdlane_f(v0, j1), d = rdlane_f(v1r, j1);
-    float inv0 = __builtin_amdgcn_rsqf(a), bia = b * inv0 * inv0;            // v_rsq_f32: 1 ulp, no refinement step on the chain
+    float inv0 = MJB_RSQF(a), bia = b * inv0 * inv0;            // v_rsq_f32: 1 ulp, no refinement step on the chain
     float d1 = __builtin_fmaxf(d - b * bia, Num<float>::minval());
-    float inv1 = __builtin_amdgcn_rsqf(d1);
+    float inv1 = MJB_RSQF(d1);
     float v1 = v1r - bia * v0;
     float L0 = c > j0 ? v0 * inv0 : (c == j0 ? a * inv0 : 0.0f);
     float L1 = c > j1 ? v1 * inv1 : (c == j1 ? d1 * inv1 : 0.0f);
@@ -740,9 +764,9 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     p1[j1] = L1;
     // rank-2 trailing update of the whole matrix: acc -= [L0 L1] [L0 L1]^T
     float av = h == 0 ? L0 : L1;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-av, av, acc, 0, 0, 0);
+    acc = MJB_MFMA(-av, av, acc);
   }
-  unsigned long long tq2 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tq2 = pf ? MJB_MEMTIME() : 0;
   if (h == 0 && c_ < n) dinv[c_] = myinv;
   gsync<64>();
   if (x) {                                                    // backward substitution L^T x = y from the packed factor in LDS
@@ -750,7 +774,7 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     if (h == 0 && c_ < n) x[c_] = rs;
     gsync<64>();
   }
-  if (pf) { unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
+  if (pf) { unsigned long long tq3 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
 }
 // x <- A^-1 x for A = M (mode 0), M + J^T D_active J (mode 1, D in dw) or M + h diag(damping) (mode 2), n <= 32, fp32.
 // The symmetric matrix lives in one 32x32 MFMA accumulator (lane (h,c): column c, rows 8q+4h+t) and is inverted in place
@@ -763,7 +787,7 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
 template <typename MRef>
 MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
   const int h = lane >> 5, c_ = lane & 31;
-  unsigned long long tq0 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tq0 = pf ? MJB_MEMTIME() : 0;
   mjb_f16v acc;
   {
     // acc[4q+t] of lane (h, c) = A[8q+4h+t][c] = A[c][8q+4h+t] (symmetric): every lane reads along its own row of M,
@@ -787,7 +811,7 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
       for (int base = 0; base < nefc; base += 64) {
         const int rix = base + lane;
         const float dl = rix < nefc ? dw[rix] : 0.0f;
-        unsigned long long act = __ballot(dl != 0.0f);
+        unsigned long long act = MJB_BALLOT(dl != 0.0f);
         float jcur = 0.0f, dcur = 0.0f;
         bool have = false;
         while (act) {
@@ -798,24 +822,24 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
           int rr = h == 0 ? ra : rb;
           float jn = J[(base + rr) * n + cm];
           float dn = h == 0 ? dA : dB;
-          if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+          if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
           jcur = c < n ? jn : 0.0f; dcur = dn; have = true;
         }
-        if (have) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dcur * jcur, jcur, acc, 0, 0, 0);
+        if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
       }
     }
   }
-  unsigned long long tq1 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tq1 = pf ? MJB_MEMTIME() : 0;
 #pragma unroll
   for (int jb = 0; jb < 16; jb++) {
     const int j0 = 2 * jb, j1 = j0 + 1, hj = (j0 >> 2) & 1, ij = 4 * (j0 >> 3) + (j0 & 3);
     if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
     int c = c_, ln = lane;
-    asm volatile("" : "+v"(c), "+v"(ln));                     // keep the per-column lane compares in the loop (cheaper than spilled masks)
+    MJB_OPAQUE2(c, ln);                     // keep the per-column lane compares in the loop (cheaper than spilled masks)
     float u0 = half_bcast(acc[ij], hj), u1 = half_bcast(acc[ij + 1], hj);
     float a = __builtin_fmaxf(rdlane_f(u0, j0), Num<float>::minval()), b = rdlane_f(u0, j1), d = rdlane_f(u1, j1);
     float det = __builtin_fmaxf(a * d - b * b, a * Num<float>::minval());
-    float rdet = __builtin_amdgcn_rcpf(det);
+    float rdet = MJB_RCPF(det);
     float p00 = d * rdet, p01 = -b * rdet, p11 = a * rdet;
     float q0 = h == 0 ? p00 : p01, q1 = h == 0 ? p01 : p11;
     float u0p = c == j0 ? u0 - 1.0f : u0, u1p = c == j1 ? u1 - 1.0f : u1;
@@ -823,9 +847,9 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
     float bop = h == 0 ? u0p : u1p;
     acc[ij] -= ln == 32 * hj + j0 ? 2.0f : 0.0f;
     acc[ij + 1] -= ln == 32 * hj + j1 ? 2.0f : 0.0f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc, 0, 0, 0);
+    acc = MJB_MFMA(aop, bop, acc);
   }
-  unsigned long long tq2 = pf ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tq2 = pf ? MJB_MEMTIME() : 0;
   gsync<64>();
   {
     const float* bp = bpad + 4 * h;
@@ -833,31 +857,23 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
 #pragma unroll
     for (int t = 0; t < 4; t++) { s0 += acc[t] * bp[t]; s1 += acc[4 + t] * bp[8 + t]; s2 += acc[8 + t] * bp[16 + t]; s3 += acc[12 + t] * bp[24 + t]; }
     float s = (s0 + s1) + (s2 + s3);
-    auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    float tot = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    float tot = half_sum(s);
     if (h == 0 && c_ < n) x[c_] = -tot;                       // acc = -A^-1
     gsync<64>();
   }
-  if (pf) { unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
+  if (pf) { unsigned long long tq3 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
 }
 template <typename MRef>
 MJB_DEV void mfma_sweep_solve32(MRef, const double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 template <typename MRef>
 MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 MJB_DEV void mfma_solve32(const double*, const double*, double*, int, int) {}
-#endif
 
 // W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
 // If x != nullptr the system (factor) x = x is solved in the same pass (fused on the register path).
 template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* x);
 // true where factor_W() inverts-and-solves in registers (fp32, one wave per environment, nv <= 32) and leaves NO factor in W
-template <typename T, int G> MJB_DEV bool fused_inverse_path(int nv) {
-#ifndef MJB_HOST_EMU
-  return G == 64 && sizeof(T) == 4 && nv <= 32;
-#else
-  return false;
-#endif
-}
+template <typename T, int G> MJB_DEV bool fused_inverse_path(int nv) { return G == 64 && sizeof(T) == 4 && nv <= 32; }
 template <typename T, int G> MJB_DEV void factor_W(Ctx<T>& c, int mode, T* x) {
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -871,7 +887,6 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
   T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *dw = w + L.efc_jv;
   if (G == 64) {
-#ifndef MJB_HOST_EMU
     if (nv <= 32) {
       // M and M + hD are well conditioned: in-register sweep inverse.  The Hessian (contact stiffness on a few dofs) keeps
       // the backward-stable Cholesky, whose packed factor in W is reused while the active set does not change.
@@ -885,7 +900,6 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
       else reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
       return;
     }
-#endif
     tile_factor<T, 8, ModelRef<T>>(m, M, W, w + L.tmp, w + L.cholcol, J, dw, nefc, mode, nv, lane);
     if (x) chol_solve<T, G>(W, w + L.tmp, x, nv, lane);
     return;
@@ -1925,22 +1939,12 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
 // ---------------------------------------------------------------------------
 // (J^T f)_i for dof i = lane & 31 on the split path (one wavefront per environment, nv <= 32): the rows are split between
 // the two 32-lane halves and the partial sums exchanged with v_permlane32_swap - half the serial length of the dot.
-template <typename T, int G> MJB_DEV bool jt_split(int nv) {
-#ifndef MJB_HOST_EMU
-  return G == 64 && nv <= 32;
-#else
-  return false;
-#endif
-}
+template <typename T, int G> MJB_DEV bool jt_split(int nv) { return G == 64 && nv <= 32; }
 template <typename T, int G> MJB_DEV T jt_dot(const T* J, const T* f, int nefc, int nv, int lane) {
-#ifndef MJB_HOST_EMU
   const int h = lane >> 5, i = lane & 31, n2 = (nefc + 1) >> 1;
   const int r0 = h ? n2 : 0, cnt = h ? nefc - n2 : n2;
   T p = i < nv ? dot_lds(J + r0 * nv + i, nv, VecLds<T>{f + r0}, cnt) : (T)0;
   return half_sum(p);
-#else
-  return (T)0;
-#endif
 }
 
 template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, bool store) {
@@ -2005,9 +2009,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
   c.pacc[PH_CNT_DIR] += 1; if (rebuild) c.pacc[PH_CNT_FACT] += 1;
 #endif
   if (rebuild) factor_W<T, G>(c, 1, search);
-#ifndef MJB_HOST_EMU
   else if (fused_inverse_path<T, G>(nv)) { gsync<G>(); mfma_solve32(W, w + L.tmp, search, nv, lane); }
-#endif
   else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
   for (int i = lane; i < nv; i += G) search[i] = -search[i];
   gsync<G>();

@@ -174,3 +174,34 @@ def test_parallel_capsules_two_contacts_in_the_kernel_source():
     for s in range(5):
         od.step(); e.step()
     assert np.abs(e.qpos - od.qpos).max() < 1e-11
+
+
+def test_fp32_mfma_solver_paths_run_on_the_cpu(compiled):
+    """The fp32 hot path itself (one wavefront per environment, nv <= 32): sweep inverse of M and M + hD in the emulated 32x32x2 MFMA
+    accumulator, MFMA Cholesky of the Newton Hessian with fused forward / blocked backward substitution, reuse solves from the packed
+    factor, J^T f split over the wave halves — executed by the CPU suite through the emulated wave intrinsics (the
+    host emulation used to switch exactly these paths off).  Against the float64 oracle at fp32 tolerances, humanoid with foot contacts."""
+    cm = compiled("humanoid")
+    od = mjo.OracleData(mjo.OracleModel(cm))
+    e = EmuEnv(cm, G=64, use_double=False, ncon_max=24, nefc_max=64)
+    rng = np.random.default_rng(2)
+    for s in range(3):                                       # a few random-ctrl steps into the foot contacts, teacher-forced
+        u = od.random_ctrl(0, 0, s, 1.0)
+        od.ctrl[:] = u
+        e.qpos[:] = od.qpos; e.qvel[:] = od.qvel; e.qacc_warmstart[:] = od.qacc_warmstart; e.ctrl[:cm.nu] = u
+        if s == 2:
+            od.forward(); e.forward()
+            assert e.counters[1] == od.counters()["nefc"] >= 4                      # constraint rows: the Hessian path is taken
+            scale = max(1.0, np.abs(od.qacc).max())
+            assert np.abs(e.qacc_smooth - od.qacc_smooth).max() < 2e-5 * max(1.0, np.abs(od.qacc_smooth).max())      # sweep inverse of M
+            assert np.abs(e.qacc - od.qacc).max() < 5e-5 * scale                                                      # MFMA Cholesky Newton steps
+            assert np.abs(e.qfrc_constraint - od.qfrc_constraint).max() < 5e-5 * max(1.0, np.abs(od.qfrc_constraint).max())
+        od.step(); e.step()
+        assert np.abs(e.qpos - od.qpos).max() < 2e-6 and np.abs(e.qvel - od.qvel).max() < 2e-3     # one-step fp32 bounds (sweep of M + hD in Euler)
+    assert e.counters[2] >= 1                                # Newton iterations were needed
+    # free-running for a few steps: stays at the fp32 level
+    for s in range(3, 8):
+        u = od.random_ctrl(0, 0, s, 1.0)
+        od.ctrl[:] = u; e.ctrl[:cm.nu] = u
+        od.step(); e.step()
+    assert np.abs(e.qpos - od.qpos).max() < 2e-5
