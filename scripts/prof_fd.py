@@ -14,3 +14,11 @@ for name, B, scale in (("humanoid", 512, 1.0), ("cartpole", 512, 0.01)):
     for _ in range(6):
         sim.transition_fd(1e-6, True)
     sim.sync()
+    # the two other float64 helper kernels, for the kernel-trace: Jacobians (k_jac) and the device observation gather (k_obs)
+    import torch
+    sim.jac([1, 2, 3], [1, 1, 1])
+    spec = sim.make_obs_spec(3, body_ids=[1])
+    out = torch.empty((B, spec.dim), device="cuda", dtype=torch.float32)
+    for _ in range(3):
+        sim.obs_gather(spec, out.data_ptr())
+    sim.sync()
