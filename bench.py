@@ -102,7 +102,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--global-batch", type=int, default=4096)
-    ap.add_argument("--chunk", type=int, default=100, help="simulation steps fused per kernel launch")
+    ap.add_argument("--chunk", type=int, default=1000, help="simulation steps fused per kernel launch (default: the whole 1000-step rollout in ONE launch)")
+    ap.add_argument("--obs-every", type=int, default=100, help="an observation row (ObservationExtractor output) is written in-kernel every this many steps and all-gathered per launch")
     ap.add_argument("--weak", action="store_true", help="fixed per-GPU batch (= --global-batch per rank) instead of sharding it")
     ap.add_argument("--model", default="humanoid", choices=["humanoid", "cartpole", "drone2", "pendulum"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -169,7 +170,7 @@ def main() -> None:
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            obs = env.rollout(n, obs_every=n)             # [1, b_local, obs_dim] on the GPU
+            obs = env.rollout(n, obs_every=min(args.obs_every, n))      # [n / obs_every, b_local, obs_dim] on the GPU (in-kernel ring)
             if events is not None:
                 e1.record()
                 events.append((e0, e1, n))
@@ -207,7 +208,7 @@ def main() -> None:
             done = 0
             while done < nsteps:
                 n = min(chunk, nsteps - done)
-                all_gather_obs(wenv.rollout(n, obs_every=n), counts=wcounts)
+                all_gather_obs(wenv.rollout(n, obs_every=min(args.obs_every, n)), counts=wcounts)
                 done += n
 
         wrun(args.warmup)
@@ -244,7 +245,8 @@ def main() -> None:
         bytes_obs = 4 * obs_dim
         avg_ms = float(np.mean(kernel_ms))
         avg_steps = float(np.mean(steps_per_launch))
-        launch_bytes = count * (bytes_step * avg_steps + bytes_obs)          # one obs row per env per launch
+        obs_rows = max(1.0, avg_steps // min(args.obs_every, max(1, int(avg_steps))))
+        launch_bytes = count * (bytes_step * avg_steps + bytes_obs * obs_rows)   # obs rows per env per launch: steps // obs_every
         achieved = launch_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC profiles (separate --pmc passes, profiles/traffic.json): only a record measured
         # with the SAME model, batch and steps per launch as the launches timed here is quoted; anything else is null
@@ -276,9 +278,10 @@ def main() -> None:
             "config": {"workload": f"examples/{args.model} random-ctrl rollout (BASELINE.json configs[2])" if args.model == "humanoid"
                        else f"examples/{args.model} random-ctrl rollout",
                        "global_batch": global_batch, "per_gpu_batch": count, "rollout_steps": args.steps,
-                       "fused_steps_per_launch": chunk, "obs_dim": obs_dim, "parallelism": f"env-shard x{ws}",
+                       "fused_steps_per_launch": chunk, "obs_every": args.obs_every, "obs_dim": obs_dim, "parallelism": f"env-shard x{ws}",
                        "lanes_per_env": sim.lanes, "lds_bytes_per_env": sim.lds_bytes_per_env,
-                       "nefcmax": sim.nefcmax, "nconmax": sim.nconmax, "specialized_kernel": bool(sim.specialized)},
+                       "nefcmax": sim.nefcmax, "nconmax": sim.nconmax, "specialized_kernel": bool(sim.specialized),
+                       "work_schedule": sim.schedule_info()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("mjb_k_step_spec (k_step<float,float,%d> with the model's sizes/offsets folded in)" if sim.specialized else "mjb::k_step<float,float,%d>") % sim.lanes,
                          "traffic_source": traffic_source, "launch_steps": avg_steps, "launches_timed": len(kernel_ms), "launches_in_timed_region": in_region,

@@ -182,6 +182,13 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
  * and efc_type (int32 out).  Call mjb_debug_forward() first. */
 /* diagnostic build (-DMJB_PROFILE) only: per-phase shader-cycle sums since the last call, host_out[24]; zeros otherwise */
 int mjb_profile_get(mjbData* d, unsigned long long* host_out);
+/* How the last stepping launch (mjb_step / mjb_rollout / mjb_step_host) mapped work to workgroups: out5 = { steps of the launch,
+ * environment blocks, resident workgroup slots of the step kernel on this device (0 = unknown), chunk_steps (0 = static map: one
+ * workgroup per block for all steps; > 0 = the resident workgroups drew (block, chunk) tickets), fair_bit (0 = hardware age order) }.
+ * The engine picks the map itself (more blocks than slots -> tickets); MJB_CHUNK_STEPS / MJB_FAIR_BIT override it for experiments. */
+int mjb_step_schedule(mjbData* d, int* out5);
+/* diagnostic kernel (-DMJB_TIMELINE) only: per environment [start, end] of its wave in the last launch (100 MHz clock), HW_ID, XCC_ID */
+int mjb_profile_env_get(mjbData* d, unsigned long long* host_out /* [batch, 4] */);
 int mjb_debug_forward(mjbData* d);
 int mjb_debug_get(mjbData* d, const char* name, void* host_out, long capacity_elems);
 

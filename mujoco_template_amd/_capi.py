@@ -93,6 +93,10 @@ def load_library() -> ctypes.CDLL:
     L.mjb_jac.argtypes = [vp, ci, vp, vp, vp, vp]
     L.mjb_profile_get.argtypes = [vp, vp]
     L.mjb_profile_get.restype = ci
+    L.mjb_profile_env_get.argtypes = [vp, vp]
+    L.mjb_step_schedule.argtypes = [vp, vp]
+    L.mjb_step_schedule.restype = ci
+    L.mjb_profile_env_get.restype = ci
     L.mjb_debug_forward.argtypes = [vp]
     L.mjb_debug_get.argtypes = [vp, ctypes.c_char_p, vp, cl]
     pcl = ctypes.POINTER(cl)
@@ -596,6 +600,18 @@ class BatchSim:
     def profile_get(self) -> np.ndarray:
         out = np.zeros(24, dtype=np.uint64)
         _check(load_library().mjb_profile_get(self.ptr, out.ctypes.data))
+        return out
+
+    def schedule_info(self) -> dict:
+        """How the last stepping launch mapped work to workgroups (``mjb_step_schedule``)."""
+        out = np.zeros(5, dtype=np.int32)
+        _check(load_library().mjb_step_schedule(self.ptr, out.ctypes.data))
+        return {"launch_steps": int(out[0]), "env_blocks": int(out[1]), "resident_slots": int(out[2]), "chunk_steps": int(out[3]),
+                "map": "tickets" if out[3] > 0 else "static", "fair_bit": int(out[4])}
+
+    def profile_env_get(self) -> np.ndarray:
+        out = np.zeros((self.batch, 4), dtype=np.uint64)
+        _check(load_library().mjb_profile_env_get(self.ptr, out.ctypes.data))
         return out
 
     def debug_forward(self) -> None:

@@ -7,4 +7,13 @@ hipError_t launch_step<float, float>(int G, const DevModel<float>* m, const Lay*
   MJB_DISPATCH_G(G, return (launch_step_g<float, float, GG>(m, Ldev, L, d, dbg, a, obs, obs_out, stream)));
   return hipErrorInvalidValue;
 }
+template <>
+int step_blocks_per_cu<float, float>(int G, const Lay& L) {
+  switch (G) {
+    case 8: return step_blocks_per_cu_g<float, float, 8>(L);
+    case 16: return step_blocks_per_cu_g<float, float, 16>(L);
+    case 64: return step_blocks_per_cu_g<float, float, 64>(L);
+  }
+  return 0;
+}
 }  // namespace mjb

@@ -92,6 +92,11 @@ struct mjbData {
   // per-model specialised fp32 step kernel (mjb_spec_load); null = generic kernel
   hipModule_t spec_mod = nullptr;
   hipFunction_t spec_fn = nullptr;
+  // work scheduling of k_step (launch()): resident workgroups of the kernel in use on this device; < 0 = not yet queried
+  long step_slots = -1;
+  int sched_chunk = -1, fair_bit = -1;     // experiment overrides (MJB_CHUNK_STEPS, MJB_FAIR_BIT); -1 = policy below
+  unsigned launch_seq = 0;                 // ticket launches so far (tags of the hand-over buffer)
+  int last_sched[5] = {0, 0, 0, 0, 0};     // of the last mode-0 launch: steps, environment blocks, resident slots, chunk_steps, fair_bit
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   double *fd_A_host = nullptr, *fd_B_host = nullptr;          // pinned: the (A, B) blocks leave the device in one async copy each
@@ -187,7 +192,9 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   rc |= dev_alloc(d, &s.subtree_com, B * h.nbody * 3); rc |= dev_alloc(d, &s.sensordata, B * h.nsensordata);
   rc |= dev_alloc(d, &s.qfrc_inverse, B * h.nv); rc |= dev_alloc(d, &s.actuator_moment, B * h.nu * h.nv);
   rc |= dev_alloc(d, &s.counters, B * CNT_N); rc |= dev_alloc(d, &s.flags, 1);
-  rc |= dev_alloc(d, &s.prof, (size_t)PH_N);
+  rc |= dev_alloc(d, &s.sched, 1);
+  if (sizeof(TS) == 4) rc |= dev_alloc(d, &s.xfer, B * (size_t)(h.nq + 3 * h.nv + 2)); else s.xfer = nullptr;
+  rc |= dev_alloc(d, &s.prof, (size_t)PH_N + 4 * B);        // + per-environment timeline records of the -DMJB_TIMELINE diagnostic kernel
   if (rc) return -1;
   auto& A = d->arrays;
   A["qpos"] = {s.qpos, h.nq, 0}; A["qvel"] = {s.qvel, h.nv, 0}; A["ctrl"] = {s.ctrl, h.nu, 0}; A["qacc"] = {s.qacc, h.nv, 0};
@@ -290,10 +297,63 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
   return s;
 }
 
-int launch(mjbData* d, const StepArgs& a, const ObsSpecDev& obs, void* obs_out, bool debug) {
+// How k_step's work is mapped to workgroups (mjb_kernels.hpp).  With no more environment blocks than the chip holds at once every
+// block keeps its workgroup for the whole launch; beyond that the resident workgroups draw (block, chunk-of-steps) tickets, which
+// removes the "rounds" of the static map and their tails (profiles/r02_wave_timeline.log: -20 % launch time at 20 steps per launch,
+// -9 % at 100, humanoid B = 4096).  Chunk length ~ sqrt(steps)/2: per-chunk cost (state through memory, one ticket) ~2 us against
+// a tail of half a chunk.  The priority hand-over (StepArgs::fair_bit) matters where the launch waits for its slowest wave.
+static void choose_schedule(mjbData* d, StepArgs& a) {
+  a.chunk_steps = 0; a.fair_bit = 0; a.nblk = 0; a.grid_blocks = 0;
+  if (a.mode != 0) return;
+  if (d->sched_chunk == -1) {
+    const char* e1 = std::getenv("MJB_CHUNK_STEPS"); const char* e2 = std::getenv("MJB_FAIR_BIT");
+    d->sched_chunk = e1 ? std::atoi(e1) : -2; d->fair_bit = e2 ? std::atoi(e2) : -2;
+  }
+  const int epb = 64 / d->G;
+  const long nblk = (d->batch + epb - 1) / epb;
+  if (d->step_slots < 0) {
+    int ncu = 0, nb = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || ncu < 1) ncu = 256;
+    if (d->dtype == MJB_F32 && d->spec_fn) {
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d->spec_fn, 64, (size_t)epb * d->Lf.bytes) != hipSuccess) nb = 0;
+    } else nb = d->dtype == MJB_F32 ? step_blocks_per_cu<float, float>(d->G, d->Lf) : step_blocks_per_cu<double, double>(d->G, d->Ld);
+    d->step_slots = nb > 0 ? (long)nb * ncu : 0;              // 0 = unknown: keep the static map
+  }
+  a.fair_bit = d->fair_bit >= 0 ? d->fair_bit : 15;            // 2^15 x 10 ns = 0.33 ms per turn
+  a.nblk = (int)nblk; a.grid_blocks = d->step_slots > 0 && d->step_slots < nblk ? (int)d->step_slots : (int)nblk;
+  if (d->sched_chunk >= 0) {
+    a.chunk_steps = a.nstep > 1 ? d->sched_chunk : 0;
+    if (std::getenv("MJB_SCHED_DEBUG")) std::fprintf(stderr, "[mjb] schedule (override): blocks %ld, resident slots %ld, steps %d -> chunk_steps %d, fair_bit %d\n", nblk, d->step_slots, a.nstep, a.chunk_steps, a.fair_bit);
+    return;
+  }
+  if (d->step_slots > 0 && nblk > d->step_slots && a.nstep >= 4) {
+    // launch time ~ T0 + switches x (cost of a switch ~ 2.7 us: hand-over out, one ticket, hand-over in) + half a chunk of tail
+    // -> c ~ sqrt(0.45 N): 3 at N = 20, 7 at N = 100 (measured optimum 3 and 6..8: profiles/r02_schedule.log)
+    int c = (int)std::lround(std::sqrt(0.45 * (double)a.nstep));
+    a.chunk_steps = c < 1 ? 1 : (c > 32 ? 32 : c);
+  }
+  if (std::getenv("MJB_SCHED_DEBUG")) std::fprintf(stderr, "[mjb] schedule: blocks %ld, resident slots %ld, steps %d -> chunk_steps %d, fair_bit %d\n", nblk, d->step_slots, a.nstep, a.chunk_steps, a.fair_bit);
+}
+
+int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_out, bool debug) {
   int rc = refresh_options(d);
   if (rc != MJB_OK) return rc;
   hipError_t e;
+  StepArgs a = a_in;
+  choose_schedule(d, a);
+  if (a.chunk_steps > 0) {
+    if (d->dtype != MJB_F32 || (long)(a.nstep / a.chunk_steps) >= (1L << 20) - 2) a.chunk_steps = 0;     // hand-over words are (fp32, tag) pairs; 20 bits of chunk index
+  }
+  if (a.mode == 0) {
+    const int epb = 64 / d->G;
+    d->last_sched[0] = a.nstep; d->last_sched[1] = (d->batch + epb - 1) / epb; d->last_sched[2] = (int)(d->step_slots > 0 ? d->step_slots : 0);
+    d->last_sched[3] = a.chunk_steps; d->last_sched[4] = a.fair_bit;
+  }
+  if (a.chunk_steps > 0) {
+    do { d->launch_seq++; } while ((d->launch_seq & 0xFFFu) == 0);
+    a.tagbase = (d->launch_seq & 0xFFFu) << 20;
+    HIPCHK(hipMemsetAsync(d->df.sched, 0, sizeof(unsigned), d->stream));
+  }
   if (d->dtype == MJB_F32 && d->spec_fn) {               // per-model specialised kernel: same arguments, same grid
     DevDebug<float> dbgarg; std::memset(&dbgarg, 0, sizeof(dbgarg));
     if (debug) dbgarg = d->dbgf;
@@ -301,7 +361,8 @@ int launch(mjbData* d, const StepArgs& a, const ObsSpecDev& obs, void* obs_out, 
     DevData<float> dv = d->df; StepArgs av = a; ObsSpecDev ov = obs; float* oo = (float*)obs_out;
     void* args[] = {(void*)&mg, (void*)&lg, (void*)&dv, (void*)&dbgarg, (void*)&av, (void*)&ov, (void*)&oo};
     const int epb = 64 / d->G;
-    e = hipModuleLaunchKernel(d->spec_fn, (unsigned)((d->batch + epb - 1) / epb), 1, 1, 64, 1, 1, (unsigned)((size_t)epb * d->Lf.bytes), d->stream, args, nullptr);
+    const unsigned grid = a.chunk_steps > 0 ? (unsigned)a.grid_blocks : (unsigned)((d->batch + epb - 1) / epb);
+    e = hipModuleLaunchKernel(d->spec_fn, grid, 1, 1, 64, 1, 1, (unsigned)((size_t)epb * d->Lf.bytes), d->stream, args, nullptr);
   } else if (d->dtype == MJB_F32) {
     DevDebug<float> none; std::memset(&none, 0, sizeof(none));
     e = launch_step<float, float>(d->G, d->mf_dev, d->Lf_dev, d->Lf, d->df, debug ? d->dbgf : none, a, obs, (float*)obs_out, d->stream);
@@ -545,13 +606,13 @@ int mjb_spec_load(mjbData* d, const void* image, long nbytes) {
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("hipModuleLoadData: ") + hipGetErrorString(e));
   e = hipModuleGetFunction(&fn, mod, "mjb_k_step_spec");
   if (e != hipSuccess) { hipModuleUnload(mod); return fail(MJB_ERR_DEVICE, "code object has no mjb_k_step_spec kernel"); }
-  d->spec_mod = mod; d->spec_fn = fn;
+  d->spec_mod = mod; d->spec_fn = fn; d->step_slots = -1;        // occupancy of the kernel in use changed
   return MJB_OK;
 }
 
 int mjb_spec_unload(mjbData* d) {
   if (!d) return fail(MJB_ERR_ARG, "data is NULL");
-  if (d->spec_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; }
+  if (d->spec_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; d->step_slots = -1; }
   return MJB_OK;
 }
 
@@ -1063,6 +1124,21 @@ int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [24] per-phase c
   void* p = d->dtype == MJB_F32 ? (void*)d->df.prof : (void*)d->dd.prof;
   HIPCHK(hipMemcpy(host_out, p, sizeof(unsigned long long) * PH_N, hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(p, 0, sizeof(unsigned long long) * PH_N));
+  return MJB_OK;
+}
+
+int mjb_step_schedule(mjbData* d, int* out5) {
+  if (!d || !out5) return fail(MJB_ERR_ARG, "NULL argument");
+  for (int i = 0; i < 5; i++) out5[i] = d->last_sched[i];
+  return MJB_OK;
+}
+
+int mjb_profile_env_get(mjbData* d, unsigned long long* host_out /* [batch, 4]: start, end (100 MHz), HW_ID, XCC_ID; zeros unless the kernel was built with -DMJB_TIMELINE */) {
+  if (!d || !host_out) return fail(MJB_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  unsigned long long* p = (d->dtype == MJB_F32 ? d->df.prof : d->dd.prof) + PH_N;
+  HIPCHK(hipMemcpy(host_out, p, sizeof(unsigned long long) * 4 * (size_t)d->batch, hipMemcpyDeviceToHost));
   return MJB_OK;
 }
 

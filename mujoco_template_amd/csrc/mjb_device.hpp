@@ -2396,31 +2396,93 @@ template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c
 // ---------------------------------------------------------------------------
 // the per-environment driver: load -> nstep x (ctrl, forward, integrate) -> store
 // ---------------------------------------------------------------------------
+// Hand-over of an environment between the chunks of ONE launch (ticket mode of k_step, mjb_kernels.hpp): the wave that ends chunk
+// k - 1 and the wave that starts chunk k may sit on different XCDs, so the words travel as 64-bit (value, tag) pairs written and
+// read with agent-scope relaxed atomics (single-copy atomic, coherent across the XCDs' L2s): tag = tagbase + chunk index is unique
+// per launch and chunk, every word validates itself, no flag, no fence, and the producer never waits for its stores.
+//   xfer[env, j],  j over  qpos | qvel | qacc_warmstart | qacc | time (lo, hi)          (ctrl is either regenerated every step or
+//   constant over the launch and read from its array)
+#ifndef MJB_HOST_EMU
+MJB_DEV unsigned long long xfer_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MJB_DEV void xfer_st(unsigned long long* p, unsigned bits, unsigned tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
+// steps [s_begin, s_end) of the launch's a.nstep.  tag_in != 0: the state comes from the hand-over buffer (written by the wave that
+// ran the steps before s_begin); tag_out != 0: it goes there, else to the state arrays and this call ends the launch for the
+// environment (counters, kinematic outputs, dumps).
 template <typename T, typename TS, int G>
 MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
-                     const ObsSpecDev& obs, TS* obs_out, T* w, int* wi, int env, int lane) {
+                     const ObsSpecDev& obs, TS* obs_out, T* w, int* wi, int env, int lane, int s_begin, int s_end, unsigned tag_in, unsigned tag_out,
+                     unsigned long long* tlacc = nullptr) {
   Ctx<T> c(mp, lp, w, wi, lane);
   ModelRef<T> m = *mp; LayRef L = *lp;
   MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
   const int nq = m.nq, nv = m.nv, nu = m.nu;
-  for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
-  for (int i = lane; i < nv; i += G) {
-    w[L.qvel + i] = (T)d.qvel[(size_t)env * nv + i];
-    w[L.qacc_ws + i] = (T)d.qacc_warmstart[(size_t)env * nv + i];
-    w[L.qacc + i] = (T)d.qacc[(size_t)env * nv + i];
+  double time;
+  bool staged_in = false;
+#ifndef MJB_HOST_EMU
+  if constexpr (sizeof(T) == 4 && sizeof(TS) == 4) {
+    if (tag_in != 0) {
+      staged_in = true;
+      const unsigned long long* x = d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2);
+      unsigned tlo = 0, thi = 0;
+      for (unsigned spins = 0;; spins++) {
+        bool ok = true;
+        for (int i = lane; i < nq; i += G) { const unsigned long long v = xfer_ld(x + i); ok = ok && (unsigned)(v >> 32) == tag_in; w[L.qpos + i] = __uint_as_float((unsigned)v); }
+        for (int i = lane; i < nv; i += G) {
+          const unsigned long long v0 = xfer_ld(x + nq + i), v1 = xfer_ld(x + nq + nv + i), v2 = xfer_ld(x + nq + 2 * nv + i);
+          ok = ok && (unsigned)(v0 >> 32) == tag_in && (unsigned)(v1 >> 32) == tag_in && (unsigned)(v2 >> 32) == tag_in;
+          w[L.qvel + i] = __uint_as_float((unsigned)v0); w[L.qacc_ws + i] = __uint_as_float((unsigned)v1); w[L.qacc + i] = __uint_as_float((unsigned)v2);
+        }
+        {                                                          // the clock: every lane reads the same two words
+          const unsigned long long v0 = xfer_ld(x + nq + 3 * nv), v1 = xfer_ld(x + nq + 3 * nv + 1);
+          ok = ok && (unsigned)(v0 >> 32) == tag_in && (unsigned)(v1 >> 32) == tag_in;
+          tlo = (unsigned)v0; thi = (unsigned)v1;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;          // every word of every environment of this wave carries the tag
+        // the steps before s_begin are held by a wave with a smaller ticket, which is running: wait (bounded: a wave that gives up
+        // flags the launch, bit 3 of the engine flags, and goes on with what it has)
+        if (spins > (1u << 20)) { if (lane == 0 && d.flags) atomicOr(d.flags, 8); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      time = __longlong_as_double((long long)(((unsigned long long)thi << 32) | tlo));
+    }
+  }
+#endif
+  if (!staged_in) {
+    for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
+    for (int i = lane; i < nv; i += G) {
+      w[L.qvel + i] = (T)d.qvel[(size_t)env * nv + i];
+      w[L.qacc_ws + i] = (T)d.qacc_warmstart[(size_t)env * nv + i];
+      w[L.qacc + i] = (T)d.qacc[(size_t)env * nv + i];
+    }
+    time = d.time[env];
   }
   for (int i = lane; i < nu; i += G) w[L.ctrl + i] = a.ctrl_mode == CTRL_ZERO ? (T)0 : (T)d.ctrl[(size_t)env * nu + i];
   for (int i = lane; i < nv * nv; i += G) w[L.M + i] = 0;       // structural zeros of the mass matrix (crb_factor fills the rest)
-  double time = d.time[env];
   int badqpos = 0, badqvel = 0, badqacc = 0;
   gsync<G>();
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   c.pt = __builtin_amdgcn_s_memtime();
 #endif
-  const int nstep = a.mode != 0 ? 1 : a.nstep;
+  if (a.mode != 0) { s_begin = 0; s_end = 1; }
   c.skip_dynamics = a.mode == 2;
   const int nstage = (a.mode == 0 && m.integrator == INT_RK4) ? 4 : 1;
-  for (int s = 0; s < nstep; s++) {
+#ifndef MJB_HOST_EMU
+  const unsigned hwslot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_ID[3:0]: this wave's slot on its SIMD
+#endif
+  for (int s = s_begin; s < s_end; s++) {
+#ifndef MJB_HOST_EMU
+    // Issue priority of the SIMD's co-resident waves: the hardware arbitrates VALU issue by priority, then AGE, so of two waves that
+    // start together the older one runs ~10 % faster for its whole life and the launch waits for the younger (profiles/r02_wave_timeline.log).
+    // Bit `fair_bit` of the 100 MHz wall clock, which all waves read alike, hands the priority back and forth between odd and even slots.
+    if (a.fair_bit > 0) {
+      const unsigned ph = (unsigned)(__builtin_amdgcn_s_memrealtime() >> (unsigned)a.fair_bit);
+      if ((ph + hwslot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     if (a.mode == 0) {
       if (group_bad<T, G>(w + L.qpos, nq, lane)) { badqpos++; reset_state<T, G>(c); time = 0; }
       if (group_bad<T, G>(w + L.qvel, nv, lane)) { badqvel++; reset_state<T, G>(c); time = 0; }
@@ -2443,6 +2505,9 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     if (a.mode != 0) break;
     if (nstage == 1) euler<T, G>(c);
     MJB_STAMP(c, PH_INTEG);
+#if defined(MJB_TIMELINE) && !defined(MJB_HOST_EMU)
+    if (tlacc) *tlacc += ((unsigned long long)(unsigned)c.niter << 8) | ((unsigned long long)(unsigned)c.nefc << 24) | ((unsigned long long)(unsigned)c.ncon << 44);
+#endif
     time += a.dt;
     if (a.obs_every > 0 && ((s + 1) % a.obs_every) == 0) {
       size_t slot = (size_t)((s + 1) / a.obs_every - 1);
@@ -2451,6 +2516,40 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
   }
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   if (lane == 0 && d.prof) for (int k = 0; k < PH_N; k++) atomicAdd(d.prof + k, c.pacc[k]);
+#endif
+  // the accumulating counters are almost always zero: device-scope atomics only when there is something to add
+  if (lane == 0) {
+    int* cn = d.counters + (size_t)env * CNT_N;
+#ifndef MJB_HOST_EMU
+    if (c.con_dropped) atomicAdd(cn + CNT_CON_DROPPED, c.con_dropped);
+    if (c.efc_dropped) atomicAdd(cn + CNT_EFC_DROPPED, c.efc_dropped);
+    if (badqpos) atomicAdd(cn + CNT_BADQPOS, badqpos);
+    if (badqvel) atomicAdd(cn + CNT_BADQVEL, badqvel);
+    if (badqacc) atomicAdd(cn + CNT_BADQACC, badqacc);
+    const int fl = (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0);
+    if (fl && d.flags) atomicOr(d.flags, fl);                  // rare: the host reads ONE word instead of the [batch, 8] counters
+#else
+    cn[CNT_CON_DROPPED] += c.con_dropped; cn[CNT_EFC_DROPPED] += c.efc_dropped;
+    cn[CNT_BADQPOS] += badqpos; cn[CNT_BADQVEL] += badqvel; cn[CNT_BADQACC] += badqacc;
+#endif
+  }
+#ifndef MJB_HOST_EMU
+  if constexpr (sizeof(T) == 4 && sizeof(TS) == 4) {
+    if (tag_out != 0) {                                        // hand the environment to whoever draws its next chunk
+      unsigned long long* x = d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2);
+      for (int i = lane; i < nq; i += G) xfer_st(x + i, __float_as_uint(w[L.qpos + i]), tag_out);
+      for (int i = lane; i < nv; i += G) {
+        xfer_st(x + nq + i, __float_as_uint(w[L.qvel + i]), tag_out);
+        xfer_st(x + nq + nv + i, __float_as_uint(w[L.qacc_ws + i]), tag_out);
+        xfer_st(x + nq + 2 * nv + i, __float_as_uint(w[L.qacc + i]), tag_out);
+      }
+      if (lane == 0) {
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(time);
+        xfer_st(x + nq + 3 * nv, (unsigned)tb, tag_out); xfer_st(x + nq + 3 * nv + 1, (unsigned)(tb >> 32), tag_out);
+      }
+      return;
+    }
+  }
 #endif
   // store state
   for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
@@ -2464,12 +2563,6 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     d.time[env] = time;
     int* cn = d.counters + (size_t)env * CNT_N;
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
-    cn[CNT_CON_DROPPED] += c.con_dropped; cn[CNT_EFC_DROPPED] += c.efc_dropped;
-    cn[CNT_BADQPOS] += badqpos; cn[CNT_BADQVEL] += badqvel; cn[CNT_BADQACC] += badqacc;
-#ifndef MJB_HOST_EMU
-    const int fl = (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0);
-    if (fl && d.flags) atomicOr(d.flags, fl);                  // rare: the host reads ONE word instead of the [batch, 8] counters
-#endif
   }
   if (a.write_kin) {
     for (int i = lane; i < 3 * m.nbody; i += G) {

@@ -111,6 +111,8 @@ struct DevData {
   int* counters;
   int* flags;                 // one sticky word for the whole batch: bit 0 contacts dropped, 1 constraint rows dropped, 2 bad-state reset
   unsigned long long* prof;   // per-phase cycle sums (diagnostic -DMJB_PROFILE build only; null otherwise)
+  unsigned* sched;            // ticket mode of k_step: [0] next ticket
+  unsigned long long* xfer;   // ticket mode: tagged hand-over buffer [batch, nq + 3 nv + 2] (env_run)
 };
 enum { PH_KIN = 0, PH_COM, PH_CRB, PH_COLL, PH_CONS, PH_VEL, PH_ACT, PH_SOLVE, PH_INTEG, PH_OTHER, PH_SOL_DIR, PH_SOL_LS, PH_CNT_LS = 12, PH_CNT_DIR, PH_CNT_FACT, PH_SOL_MV, PH_FAC_LOAD = 16, PH_FAC_PANEL, PH_FAC_BACK, PH_FAC_ALL, PH_N = 24 };
 
@@ -143,6 +145,10 @@ struct StepArgs {
   // optional ctrl noise of that law (reference lqr.py:160-165): + std[a] * table[(step + env * stride) mod nsteps][a] before the clip
   const void *fb_noise_std, *fb_noise_tab;
   int fb_nsteps, fb_env_stride;
+  int fair_bit;          // >0: alternate the issue priority of a SIMD's waves by this bit of the 100 MHz clock (env_run); 0 = leave the hardware's age order
+  unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ chunk index), unique among the launches that could still be in the buffer
+  int nblk, grid_blocks; // ticket mode: environment blocks of the batch; workgroups launched (the resident ones)
+  int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of this many steps) tickets from d.sched (mjb_kernels.hpp)
 };
 
 }  // namespace mjb

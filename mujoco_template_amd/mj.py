@@ -24,7 +24,7 @@ import numpy as np
 
 from . import mjcf
 from ._capi import MIRROR_FIELDS, BatchSim, DeviceModel
-from .exceptions import ConfigError, LinearizationError
+from .exceptions import ConfigError, LinearizationError, TemplateError
 from .mjcf import CompiledModel
 
 # ----------------------------------------------------------------------------------
@@ -265,6 +265,9 @@ class MjData:
         only fetched once it is non-zero."""
         if int(self._flags[0]) == 0:
             return
+        if int(self._flags[0]) & 8:
+            raise TemplateError("the step kernel's work scheduler gave up waiting for a chunk of steps (engine flag 8): the results of "
+                                "this launch are invalid; set MJB_CHUNK_STEPS=0 to use the static map and report the configuration")
         cn = self._sim.counters()
         msgs = []
         if int(cn["con_dropped"].sum()) or int(cn["efc_dropped"].sum()):

@@ -14,7 +14,7 @@ env = Env.from_xml_path(os.path.join(ROOT, "models/humanoid.xml"), obs_spec=Obse
 env.data.sim.use_torch_stream()
 env.rollout(200, obs_every=200)
 torch.cuda.synchronize()
-for n in (1, 2, 4, 10, 20, 50, 100):
+for n in [int(x) for x in os.environ.get("SWEEP_STEPS", "1,2,4,10,20,50,100").split(",")]:
     reps = max(5, 200 // n)
     ev = []
     for _ in range(reps):

@@ -547,3 +547,35 @@ def test_specialised_kernel_is_bitwise_identical_to_the_generic_one(world, name,
     sim.rollout(3, CTRL_ZERO)
     with pytest.raises(capi.TemplateError):
         BatchSim(dm, 4, dtype="float32", specialize=True)
+
+
+@pytest.mark.parametrize("name,B,chunk", [("humanoid", 4096, None), ("humanoid", 300, 3), ("drone2", 2050, 1), ("cartpole", 1029, 4), ("pendulum", 70, 2)])
+def test_ticket_schedule_is_bitwise_identical_to_the_static_map(world, name, B, chunk, monkeypatch):
+    """k_step's ticket mode (resident workgroups draw (environment block, chunk of steps) tickets; the state travels through the
+    tagged hand-over buffer between chunks, possibly across XCDs) computes exactly what the static map computes: states,
+    clocks, counters, kinematic outputs and the in-kernel observation ring, bit for bit.  humanoid B = 4096 takes the mode by
+    the default policy (more blocks than the chip holds); the other cases force it (MJB_CHUNK_STEPS) on 8- and 16-lane
+    models and ragged last blocks."""
+    import torch
+
+    cm, om, dm = world(name)
+    res = {}
+    for mode in ("static", "tickets"):
+        monkeypatch.setenv("MJB_CHUNK_STEPS", "0" if mode == "static" else ("" if chunk is None else str(chunk)))
+        if mode == "tickets" and chunk is None:
+            monkeypatch.delenv("MJB_CHUNK_STEPS")
+        sim = BatchSim(dm, B, dtype="float32")
+        spec = sim.make_obs_spec(1 | 2 | 16)                      # qpos | qvel | time
+        out = []
+        for launch, n in enumerate((23, 40, 7)):                  # several launches: the hand-over tags must not collide across them
+            ring = torch.zeros((n // 5 if n >= 5 else 1, B, spec.dim), dtype=torch.float32, device="cuda")
+            sim.rollout(n, CTRL_RANDOM, seed=3, step0=100 * launch, ctrl_scale=SCALE[name], obs_spec=spec, obs_out_ptr=ring.data_ptr(), obs_every=5 if n >= 5 else n)
+            sim.sync()
+            out.append(ring.cpu().numpy())
+        cn = sim.counters()
+        res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "ctrl", "time", "xpos", "sensordata")] + out + [cn[k] for k in ("ncon", "nefc", "solver_niter")]
+        sim.sync_to_host()
+        assert int(sim.host_view("engine_flags")[0]) & 8 == 0
+    for a, b in zip(res["static"], res["tickets"]):
+        assert np.array_equal(a, b)
+    assert np.isfinite(res["tickets"][0]).all() and res["tickets"][5].min() > 0
