@@ -96,6 +96,7 @@ struct mjbData {
   long step_slots = -1;
   int sched_chunk = -1, fair_bit = -1;     // experiment overrides (MJB_CHUNK_STEPS, MJB_FAIR_BIT); -1 = policy below
   unsigned launch_seq = 0;                 // ticket launches so far (tags of the hand-over buffer)
+  unsigned long long ticket_next = 0;      // value of the device ticket counter when the next ticket launch starts
   int last_sched[5] = {0, 0, 0, 0, 0};     // of the last mode-0 launch: steps, environment blocks, resident slots, chunk_steps, fair_bit
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
@@ -352,7 +353,13 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
   if (a.chunk_steps > 0) {
     do { d->launch_seq++; } while ((d->launch_seq & 0xFFFu) == 0);
     a.tagbase = (d->launch_seq & 0xFFFu) << 20;
-    HIPCHK(hipMemsetAsync(d->df.sched, 0, sizeof(unsigned), d->stream));
+    // the ticket counter is never reset on the hot path: every launched workgroup draws tickets until one is past the end, so a
+    // launch advances the counter by exactly (tickets + workgroups) and the next launch starts from there (32-bit: rewound long before it wraps)
+    const unsigned nchunk = ((unsigned)a.nstep + (unsigned)a.chunk_steps - 1) / (unsigned)a.chunk_steps;
+    const unsigned long long adv = (unsigned long long)a.nblk * nchunk + (unsigned long long)a.grid_blocks;
+    if (d->ticket_next + adv > 0xF0000000ull) { HIPCHK(hipMemsetAsync(d->df.sched, 0, sizeof(unsigned), d->stream)); d->ticket_next = 0; }
+    a.ticket_base = (unsigned)d->ticket_next;
+    d->ticket_next += adv;
   }
   if (d->dtype == MJB_F32 && d->spec_fn) {               // per-model specialised kernel: same arguments, same grid
     DevDebug<float> dbgarg; std::memset(&dbgarg, 0, sizeof(dbgarg));

@@ -146,6 +146,7 @@ struct StepArgs {
   const void *fb_noise_std, *fb_noise_tab;
   int fb_nsteps, fb_env_stride;
   int fair_bit;          // >0: alternate the issue priority of a SIMD's waves by this bit of the 100 MHz clock (env_run); 0 = leave the hardware's age order
+  unsigned ticket_base;  // ticket mode: value of d.sched[0] when this launch starts (the counter is not reset between launches)
   unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ chunk index), unique among the launches that could still be in the buffer
   int nblk, grid_blocks; // ticket mode: environment blocks of the batch; workgroups launched (the resident ones)
   int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of this many steps) tickets from d.sched (mjb_kernels.hpp)
