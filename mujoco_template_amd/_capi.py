@@ -230,7 +230,7 @@ def compile_spec(source: str, *, force: bool = False) -> str:
 
     extra = os.environ.get("MJB_SPEC_FLAGS", "").split()        # experiments, e.g. -DMJB_WPS=3 (register budget for 3 waves/SIMD)
     sched = spec_scheduler(source)
-    h = hashlib.sha1((source + " ".join(extra) + f" sched={sched}").encode())
+    h = hashlib.sha1((source + " ".join(extra) + f" sched={sched} nolicm").encode())
     for f in ("mjb_types.hpp", "mjb_device.hpp", "mjb_kernels.hpp"):
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -256,7 +256,9 @@ def compile_spec(source: str, *, force: bool = False) -> str:
             fh.write(source)
     except OSError as exc:
         raise TemplateError(f"cannot write the specialised kernel source: {exc}") from exc
-    base = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on"]
+    # -disable-machine-licm: the step kernel is one persistent loop around the whole forward pipeline; hoisting the body's literal
+    # constants out of it costs more registers than the kernel has (csrc/Makefile, STEPFLAGS)
+    base = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", "-mllvm", "-disable-machine-licm"]
     tail = [*extra, "-I", _CSRC, "-o", tmp, src]
     attempts = [[*base, "-mllvm", f"-amdgpu-sched-strategy={sched}", *tail], [*base, *tail]] if sched else [[*base, *tail]]
     err = ""

@@ -2286,7 +2286,7 @@ template <typename T, int G> MJB_DEV void random_ctrl(ModelRef<T> m, T* ctrl, un
 
 // Linear state-feedback controller evaluated on the device (the LQR law of the reference's examples,
 // examples/humanoid/controllers/lqr.py:147-170): ctrl = clip(u0 - K dx), dx = [q (-) q0 ; qvel - v0] in tangent space.
-template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, const StepArgs& a, unsigned env, unsigned step) {
+template <typename T, int G> MJB_DEV void feedback_ctrl(Ctx<T>& c, ArgsRef a, unsigned env, unsigned step) {
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nu = m.nu;
   auto K = (const T MJB_CONST*)a.fb_K; auto u0 = (const T MJB_CONST*)a.fb_u0;
   auto q0 = (const T MJB_CONST*)a.fb_q0; auto v0 = (const T MJB_CONST*)a.fb_v0;
@@ -2374,7 +2374,7 @@ template <typename T, int G> MJB_DEV void reset_state(Ctx<T>& c) {
 
 // flat observation (keys in sorted order, reference observations.py:171-174):
 // bodies_pos, ctrl, geoms_pos, qpos, qvel, sensordata, sites_pos, subtree_com, time
-template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c, const ObsSpecDev& s, double time, TS* out) {
+template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c, ObsRef s, double time, TS* out) {
   ModelRef<T> m = *c.mp; LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
   int o = 0;
   const T* bsrc = (s.flags & 64) ? w + L.xipos : w + L.xpos;
@@ -2410,11 +2410,11 @@ MJB_DEV void xfer_st(unsigned long long* p, unsigned bits, unsigned tag) {
 #endif
 
 // steps [s_begin, s_end) of the launch's a.nstep.  tag_in != 0: the state comes from the hand-over buffer (written by the wave that
-// ran the steps before s_begin); tag_out != 0: it goes there, else to the state arrays and this call ends the launch for the
-// environment (counters, kinematic outputs, dumps).
+// ran the steps before s_begin).  s_end < a.nstep (ticket mode): it goes there; else to the state arrays, and this call ends the
+// launch for the environment (counters, kinematic outputs, dumps).
 template <typename T, typename TS, int G>
-MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
-                     const ObsSpecDev& obs, TS* obs_out, T* w, int* wi, int env, int lane, int s_begin, int s_end, unsigned tag_in, unsigned tag_out,
+MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, DataRef<TS> d, DebugRef<TS> dbg, ArgsRef a,
+                     ObsRef obs, TS* obs_out, T* w, int* wi, int env, int lane, int s_begin, int s_end, unsigned tag_in,
                      unsigned long long* tlacc = nullptr) {
   Ctx<T> c(mp, lp, w, wi, lane);
   ModelRef<T> m = *mp; LayRef L = *lp;
@@ -2423,6 +2423,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
   double time;
   bool staged_in = false;
 #ifndef MJB_HOST_EMU
+#ifndef MJB_NO_XFER
   if constexpr (sizeof(T) == 4 && sizeof(TS) == 4) {
     if (tag_in != 0) {
       staged_in = true;
@@ -2451,6 +2452,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     }
   }
 #endif
+#endif
   if (!staged_in) {
     for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
     for (int i = lane; i < nv; i += G) {
@@ -2478,10 +2480,12 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     // Issue priority of the SIMD's co-resident waves: the hardware arbitrates VALU issue by priority, then AGE, so of two waves that
     // start together the older one runs ~10 % faster for its whole life and the launch waits for the younger (profiles/r02_wave_timeline.log).
     // Bit `fair_bit` of the 100 MHz wall clock, which all waves read alike, hands the priority back and forth between odd and even slots.
+#ifndef MJB_NO_FAIR
     if (a.fair_bit > 0) {
       const unsigned ph = (unsigned)(__builtin_amdgcn_s_memrealtime() >> (unsigned)a.fair_bit);
       if ((ph + hwslot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
+#endif
 #endif
     if (a.mode == 0) {
       if (group_bad<T, G>(w + L.qpos, nq, lane)) { badqpos++; reset_state<T, G>(c); time = 0; }
@@ -2533,8 +2537,10 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, c
     cn[CNT_BADQPOS] += badqpos; cn[CNT_BADQVEL] += badqvel; cn[CNT_BADQACC] += badqacc;
 #endif
   }
-#ifndef MJB_HOST_EMU
+#if !defined(MJB_HOST_EMU) && !defined(MJB_NO_XFER)
   if constexpr (sizeof(T) == 4 && sizeof(TS) == 4) {
+    // chunk k ends at s_end = (k + 1) chunk_steps: its hand-over carries tag k + 1
+    const unsigned tag_out = (a.mode == 0 && a.chunk_steps > 0 && s_end < a.nstep) ? a.tagbase + (unsigned)s_end / (unsigned)a.chunk_steps : 0u;
     if (tag_out != 0) {                                        // hand the environment to whoever draws its next chunk
       unsigned long long* x = d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2);
       for (int i = lane; i < nq; i += G) xfer_st(x + i, __float_as_uint(w[L.qpos + i]), tag_out);

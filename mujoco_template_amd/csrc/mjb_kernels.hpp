@@ -21,16 +21,16 @@ namespace mjb {
 //    chunk_steps consecutive steps.  Between its chunks an environment travels through the tagged hand-over buffer (env_run), which
 //    is also what orders the chunks: a wave that draws chunk k finds the words tagged k or re-reads until it does.  Tickets are
 //    handed out in order, so the wave it waits for holds a SMALLER ticket and never waits for this one: no cycle.
+//
+// Register pressure: the kernel sits at 256 VGPRs / ~100 SGPRs inside env_run, so NOTHING of the loop around it may stay live across
+// it (a first version kept the launch arguments and the loop's invariants in registers: +130 SGPR and +43 VGPR spills, -3.7 %).  The
+// body therefore reads the launch arguments through the kernarg segment pointer, laundered at the top of every iteration: each
+// field is a scalar load where it is used, and an iteration carries nothing over but that pointer.
 template <typename T, typename TS, int G>
-MJB_DEV void k_step_body(const DevModel<T>* mg, const Lay* lg, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a, const ObsSpecDev& obs, TS* obs_out) {
+MJB_DEV void k_step_body() {
   extern __shared__ __align__(16) char smem[];
-  const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
-  const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)mg;
-  const Lay MJB_CONST* lp = (const Lay MJB_CONST*)lg;
-  LayRef L = *lp;
-  MJB_SPEC_ASSUME_LAY(L)
-  T* w = (T*)(smem + (size_t)sub * L.bytes);
-  int* wi = (int*)(w + L.nT);
+  typedef StepKernArgs<T, TS> KA;
+  const KA MJB_CONST* kp = (const KA MJB_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
 #if defined(MJB_TIMELINE)
   const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();     // diagnostic: when did this WORKGROUP start / end, where, how much did it do
   unsigned long long tlacc = 0, tlt = 0;
@@ -39,30 +39,52 @@ MJB_DEV void k_step_body(const DevModel<T>* mg, const Lay* lg, const DevData<TS>
 #define MJB_TLACC nullptr
 #endif
   // ONE call site of env_run (the forward pipeline is inlined once): the static map is the loop below with a single pass
-  const bool tickets = a.chunk_steps > 0 && a.mode == 0;
-  const unsigned nblk = tickets ? (unsigned)a.nblk : gridDim.x, cs = tickets ? (unsigned)a.chunk_steps : (unsigned)a.nstep;
-  const unsigned nchunk = tickets ? ((unsigned)a.nstep + cs - 1) / cs : 1u, total = nblk * nchunk;
   for (;;) {
-    unsigned blk = blockIdx.x, k = 0;
+    asm volatile("" : "+s"(kp));
+    ArgsRef a = kp->a;
+    DataRef<TS> d = kp->d;
+    const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
+    const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)kp->mg;
+    const Lay MJB_CONST* lp = (const Lay MJB_CONST*)kp->lg;
+    LayRef L = *lp;
+    MJB_SPEC_ASSUME_LAY(L)
+    T* w = (T*)(smem + (size_t)sub * L.bytes);
+    int* wi = (int*)(w + L.nT);
+#ifdef MJB_NO_TICKETS                      // experiment: what does the ticket loop cost the static map?
+    const bool tickets = false;
+#else
+    const bool tickets = a.chunk_steps > 0 && a.mode == 0;
+#endif
+    unsigned blk = blockIdx.x;
+    int s0 = 0, s1 = a.nstep;
+    unsigned tag_in = 0;
     if (tickets) {
+      const unsigned nblk = (unsigned)a.nblk, cs = (unsigned)a.chunk_steps, nchunk = ((unsigned)a.nstep + cs - 1) / cs;
       unsigned t = 0;
       if (threadIdx.x == 0) t = atomicAdd(d.sched, 1u);
       t = (unsigned)__builtin_amdgcn_readfirstlane((int)t) - a.ticket_base;
-      if (t >= total) break;
-      blk = t % nblk; k = t / nblk;
+      if (t >= nblk * nchunk) break;
+      const unsigned k = t / nblk;
+      blk = t - k * nblk;
+      s0 = (int)(k * cs); s1 = k + 1 == nchunk ? a.nstep : (int)((k + 1) * cs);
+      tag_in = k > 0 ? a.tagbase + k : 0u;
     }
     const int env = (int)blk * (64 / G) + sub;
-    const int s0 = (int)(k * cs), s1 = (int)(k + 1 == nchunk ? (unsigned)a.nstep : (k + 1) * cs);
-    const unsigned tag_in = k > 0 ? a.tagbase + k : 0u, tag_out = k + 1 < nchunk ? a.tagbase + k + 1 : 0u;
-    if (env < d.batch) env_run<T, TS, G>(mp, lp, d, dbg, a, obs, obs_out, w, wi, env, lane, s0, s1, tag_in, tag_out, MJB_TLACC);
-    if (!tickets) break;
+    if (env < d.batch) env_run<T, TS, G>(mp, lp, d, kp->dbg, a, kp->obs, kp->obs_out, w, wi, env, lane, s0, s1, tag_in, MJB_TLACC);
+    asm volatile("" : "+s"(kp));                              // (not even the map's flag is carried across env_run)
+#ifdef MJB_NO_TICKETS
+    break;
+#else
+    if (!(kp->a.chunk_steps > 0 && kp->a.mode == 0)) break;
+#endif
 #if defined(MJB_TIMELINE)
     tlt++;
 #endif
   }
 #if defined(MJB_TIMELINE)
-  if (threadIdx.x == 0 && d.prof) {
-    unsigned long long* tl = d.prof + PH_N + 4 * (size_t)blockIdx.x;
+  asm volatile("" : "+s"(kp));
+  if (threadIdx.x == 0 && kp->d.prof) {
+    unsigned long long* tl = kp->d.prof + PH_N + 4 * (size_t)blockIdx.x;
     tl[0] = tl0; tl[1] = __builtin_amdgcn_s_memrealtime();
     tl[2] = __builtin_amdgcn_s_getreg((15 << 11) | 4) | (tlt << 16);   // HW_ID[15:0]: wave slot, SIMD, pipe, CU, SH, SE; tickets served
     tl[3] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) | tlacc;   // XCC_ID[3:0], sums of Newton iterations / rows / contacts
@@ -70,9 +92,10 @@ MJB_DEV void k_step_body(const DevModel<T>* mg, const Lay* lg, const DevData<TS>
 #endif
 #undef MJB_TLACC
 }
+// (the parameters are read through the kernarg segment pointer, see k_step_body; StepKernArgs mirrors this list)
 template <typename T, typename TS, int G>
 __global__ __launch_bounds__(64, MJB_WPS) void k_step(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
-  k_step_body<T, TS, G>(mg, lg, d, dbg, a, obs, obs_out);
+  k_step_body<T, TS, G>();
 }
 #ifdef MJB_SPEC_KERNEL
 }  // namespace mjb
@@ -80,7 +103,7 @@ __global__ __launch_bounds__(64, MJB_WPS) void k_step(const DevModel<T>* mg, con
 // step kernel with MJB_SPEC_ASSUME / MJB_SPEC_ASSUME_LAY pinning the sizes and LDS offsets of ONE compiled model.
 extern "C" __global__ __launch_bounds__(64, MJB_WPS) void mjb_k_step_spec(const mjb::DevModel<float>* mg, const mjb::Lay* lg, mjb::DevData<float> d, mjb::DevDebug<float> dbg,
                                                                         mjb::StepArgs a, mjb::ObsSpecDev obs, float* obs_out) {
-  mjb::k_step_body<float, float, MJB_SPEC_G>(mg, lg, d, dbg, a, obs, obs_out);
+  mjb::k_step_body<float, float, MJB_SPEC_G>();
 }
 namespace mjb {
 #endif

@@ -152,4 +152,15 @@ struct StepArgs {
   int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of this many steps) tickets from d.sched (mjb_kernels.hpp)
 };
 
+// References to launch arguments as the device code takes them: objects in the constant address space (the kernarg segment), so
+// that every field read is a scalar load that can be redone where it is needed instead of a value kept live (k_step_body).
+typedef const StepArgs MJB_CONST& ArgsRef;
+typedef const ObsSpecDev MJB_CONST& ObsRef;
+template <typename TS> using DataRef = const DevData<TS> MJB_CONST&;
+template <typename TS> using DebugRef = const DevDebug<TS> MJB_CONST&;
+// the argument list of k_step / mjb_k_step_spec as one struct (same member order, same natural alignment = the kernarg layout)
+template <typename T, typename TS> struct StepKernArgs {
+  const DevModel<T>* mg; const Lay* lg; DevData<TS> d; DevDebug<TS> dbg; StepArgs a; ObsSpecDev obs; TS* obs_out;
+};
+
 }  // namespace mjb

@@ -1,0 +1,21 @@
+#!/bin/bash
+# After `bash scripts/run_profile_set_r02.sh <tag>` on the GPU box: regenerate profiles/r02_final_* from gpurun_out/<tag>/ and refresh
+# profiles/traffic.json (HBM bytes per launch, one record per launch length).
+set -e
+tag=${1:-r02}
+o=gpurun_out/$tag
+python3 scripts/summarize_profile.py r02_final $o/kt $o/pmc1 $o/pmc2 $o/pmc3 $o/pmc4 $o/pmc5 --envsteps-per-launch 4096000 --timed-launches 5 > /dev/null
+python3 scripts/summarize_profile.py r02_final_driver_shape $o/dkt $o/dpmc3 $o/dpmc4 --envsteps-per-launch 81920 --timed-launches 5 > /dev/null
+python3 scripts/summarize_profile.py r02_final_fd $o/fkt $o/fpmc1 $o/fpmc2 $o/fpmc3 $o/fpmc4 $o/fpmc5 --kernel "k_fd<double, float, 64>" --timed-launches 6 > /dev/null
+cp $o/bench.json profiles/r02_final_bench.json
+cp $o/bench_driver_shape.json profiles/r02_final_bench_driver_shape.json
+python3 - <<'PY'
+import json
+recs = []
+for name, steps, cmd, n in (("r02_final", 1000, "python3 bench.py --no-cpu-baseline --no-host-loop", 5), ("r02_final_driver_shape", 20, "python3 bench.py --no-cpu-baseline --no-host-loop --steps 20 --warmup 5", 5)):
+    s = json.load(open(f"profiles/{name}_summary.json"))
+    recs.append({"model": "humanoid", "global_batch": 4096, "launch_steps": steps, "traffic_bytes_per_launch": s["traffic_bytes_per_launch"],
+                 "source": f"profiles/{name}_summary.txt (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate --pmc passes of `{cmd}`, its {n} event-timed launches)"})
+json.dump(recs, open("profiles/traffic.json", "w"), indent=1)
+print(recs)
+PY

@@ -34,7 +34,7 @@ void run_group(const DevModel<T>& m, const Lay& L, const DevData<double>& d, con
   for (int lane = 0; lane < G; lane++) {
     th.emplace_back([&, lane]() {
       emu::tl_group = &grp; emu::tl_lane = lane;
-      env_run<T, double, G>(&m, &L, d, dbg, a, obs, obs_out, w, wi, 0, lane, 0, a.nstep, 0u, 0u);
+      env_run<T, double, G>(&m, &L, d, dbg, a, obs, obs_out, w, wi, 0, lane, 0, a.nstep, 0u);
     });
   }
   for (auto& t : th) t.join();

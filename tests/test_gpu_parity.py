@@ -573,6 +573,10 @@ def test_ticket_schedule_is_bitwise_identical_to_the_static_map(world, name, B, 
             sim.sync()
             out.append(ring.cpu().numpy())
         cn = sim.counters()
+        info = sim.schedule_info()                                # what the LAST launch (7 steps) used
+        assert info["map"] == mode and info["launch_steps"] == 7 and (info["chunk_steps"] > 0) == (mode == "tickets")
+        if chunk is None and mode == "tickets":
+            assert 0 < info["resident_slots"] < info["env_blocks"] == 4096        # the policy's reason for taking the ticket map
         res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "ctrl", "time", "xpos", "sensordata")] + out + [cn[k] for k in ("ncon", "nefc", "solver_niter")]
         sim.sync_to_host()
         assert int(sim.host_view("engine_flags")[0]) & 8 == 0
