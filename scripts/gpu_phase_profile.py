@@ -1,6 +1,7 @@
-"""Per-phase cycle shares of k_step (diagnostic build: make -C mujoco_template_amd/csrc prof; MJB_PROFILE=1)."""
+"""Per-phase cycle shares of k_step: the per-model specialised kernel compiled with in-kernel cycle stamps (MJB_SPEC_FLAGS=-DMJB_PROFILE;
+read the SHARES, the stamps themselves cost time)."""
 import os, sys
-os.environ["MJB_PROFILE"] = "1"
+os.environ["MJB_SPEC_FLAGS"] = (os.environ.get("MJB_SPEC_FLAGS", "") + " -DMJB_PROFILE").strip()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mujoco_template_amd.mjcf import compile_xml_path

@@ -9,15 +9,19 @@ mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_shape.json 2> $out/bench_driver_shape.err
 B="python3 bench.py --no-cpu-baseline --no-host-loop"
+# the SQ_* counters are 32-bit per shader engine: over a 100 ms launch (1000 fused steps) they wrap, so the instruction-mix / wait /
+# MFMA passes run the same rollout in 100-step launches; the HBM passes (KiB units) keep the bench line's own launch length
+C="python3 bench.py --no-cpu-baseline --no-host-loop --chunk 100"
 D="python3 bench.py --no-cpu-baseline --no-host-loop --steps 20 --warmup 5"
 F="python3 scripts/prof_fd.py"
 rp() { d=$1; shift; rocprofv3 "$@" > $out/$d.log 2>&1; echo "$d done"; }
 rp kt    --kernel-trace --stats --output-format csv -d $out/kt -- $B
-rp pmc1  --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $out/pmc1 -- $B
-rp pmc2  --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc2 -- $B
+rp ckt   --kernel-trace --stats --output-format csv -d $out/ckt -- $C
+rp pmc1  --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $out/pmc1 -- $C
+rp pmc2  --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc2 -- $C
 rp pmc3  --pmc FETCH_SIZE --output-format csv -d $out/pmc3 -- $B
 rp pmc4  --pmc WRITE_SIZE --output-format csv -d $out/pmc4 -- $B
-rp pmc5  --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc5 -- $B
+rp pmc5  --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc5 -- $C
 rp dkt   --kernel-trace --stats --output-format csv -d $out/dkt -- $D
 rp dpmc3 --pmc FETCH_SIZE --output-format csv -d $out/dpmc3 -- $D
 rp dpmc4 --pmc WRITE_SIZE --output-format csv -d $out/dpmc4 -- $D
