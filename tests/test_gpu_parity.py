@@ -549,13 +549,14 @@ def test_specialised_kernel_is_bitwise_identical_to_the_generic_one(world, name,
         BatchSim(dm, 4, dtype="float32", specialize=True)
 
 
-@pytest.mark.parametrize("name,B,chunk", [("humanoid", 4096, None), ("humanoid", 300, 3), ("drone2", 2050, 1), ("cartpole", 1029, 4), ("pendulum", 70, 2)])
-def test_ticket_schedule_is_bitwise_identical_to_the_static_map(world, name, B, chunk, monkeypatch):
+@pytest.mark.parametrize("name,B,chunk,spec", [("humanoid", 4096, None, None), ("humanoid", 4096, None, False), ("humanoid", 300, 3, None), ("drone2", 2050, 1, None),
+                                               ("cartpole", 1029, 4, None), ("cartpole", 1029, 2, False), ("pendulum", 70, 2, None)])
+def test_ticket_schedule_is_bitwise_identical_to_the_static_map(world, name, B, chunk, spec, monkeypatch):
     """k_step's ticket mode (resident workgroups draw (environment block, chunk of steps) tickets; the state travels through the
     tagged hand-over buffer between chunks, possibly across XCDs) computes exactly what the static map computes: states,
     clocks, counters, kinematic outputs and the in-kernel observation ring, bit for bit.  humanoid B = 4096 takes the mode by
     the default policy (more blocks than the chip holds); the other cases force it (MJB_CHUNK_STEPS) on 8- and 16-lane
-    models and ragged last blocks."""
+    models and ragged last blocks; ``spec=False`` runs the generic kernels (their own occupancy query and launcher)."""
     import torch
 
     cm, om, dm = world(name)
@@ -564,12 +565,12 @@ def test_ticket_schedule_is_bitwise_identical_to_the_static_map(world, name, B, 
         monkeypatch.setenv("MJB_CHUNK_STEPS", "0" if mode == "static" else ("" if chunk is None else str(chunk)))
         if mode == "tickets" and chunk is None:
             monkeypatch.delenv("MJB_CHUNK_STEPS")
-        sim = BatchSim(dm, B, dtype="float32")
-        spec = sim.make_obs_spec(1 | 2 | 16)                      # qpos | qvel | time
+        sim = BatchSim(dm, B, dtype="float32", specialize=spec)
+        ospec = sim.make_obs_spec(1 | 2 | 16)                     # qpos | qvel | time
         out = []
         for launch, n in enumerate((23, 40, 7)):                  # several launches: the hand-over tags must not collide across them
-            ring = torch.zeros((n // 5 if n >= 5 else 1, B, spec.dim), dtype=torch.float32, device="cuda")
-            sim.rollout(n, CTRL_RANDOM, seed=3, step0=100 * launch, ctrl_scale=SCALE[name], obs_spec=spec, obs_out_ptr=ring.data_ptr(), obs_every=5 if n >= 5 else n)
+            ring = torch.zeros((n // 5 if n >= 5 else 1, B, ospec.dim), dtype=torch.float32, device="cuda")
+            sim.rollout(n, CTRL_RANDOM, seed=3, step0=100 * launch, ctrl_scale=SCALE[name], obs_spec=ospec, obs_out_ptr=ring.data_ptr(), obs_every=5 if n >= 5 else n)
             sim.sync()
             out.append(ring.cpu().numpy())
         cn = sim.counters()
@@ -583,3 +584,22 @@ def test_ticket_schedule_is_bitwise_identical_to_the_static_map(world, name, B, 
     for a, b in zip(res["static"], res["tickets"]):
         assert np.array_equal(a, b)
     assert np.isfinite(res["tickets"][0]).all() and res["tickets"][5].min() > 0
+
+
+def test_ticket_schedule_many_hand_overs(world, monkeypatch):
+    """Stress of the tagged hand-over buffer: 250 launches of 9 steps in chunks of ONE step (every step of every environment changes
+    wave, usually XCD: ~9 M hand-overs) end in exactly the state the static map reaches, and no wave ever gave up waiting."""
+    cm, om, dm = world("humanoid")
+    B, res = 4096, {}
+    for mode, chunk in (("static", "0"), ("tickets", "1")):
+        monkeypatch.setenv("MJB_CHUNK_STEPS", chunk)
+        sim = BatchSim(dm, B, dtype="float32")
+        for launch in range(250):
+            sim.rollout(9, CTRL_RANDOM, seed=11, step0=9 * launch, ctrl_scale=SCALE["humanoid"])
+        sim.sync()
+        assert sim.schedule_info()["map"] == mode
+        sim.sync_to_host()
+        assert int(sim.host_view("engine_flags")[0]) & 8 == 0
+        res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc_warmstart", "time")]
+    for a, b in zip(res["static"], res["tickets"]):
+        assert np.array_equal(a, b)
