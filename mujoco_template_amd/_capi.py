@@ -175,13 +175,19 @@ def _source_from(fn, *args) -> str:
 
 def spec_scheduler(source: str) -> str | None:
     """The machine scheduler the specialised kernel is compiled with — a stated rule, not a retry: the iterative ILP strategy
-    for one-wave-per-environment kernels (``MJB_SPEC_G == 64``: +4 % on the humanoid, the only place it was measured to pay),
-    LLVM's default for the packed kernels (G = 8 / 16).  With the iterative strategy ROCm 7.2.0's clang crashes in the greedy
-    register allocator on the specialised G = 8 kernel of the tests' BASE_XML model (``profiles/r02_hipcc_iterative_ilp_crash.txt``)."""
+    (measured on the same box, default scheduler -> iterative: humanoid +4 %, drone2 +8 %, cart-pole +5 %) for every model that can
+    have constraints worth scheduling for (row cap ``nefc_max >= 8``, or one wave per environment); LLVM's default for the
+    degenerate ones (pendulum: 2 rows, the tests' BASE_XML: 2 rows), whose kernels are tiny and where the one compiler crash
+    with this flag was seen (ROCm 7.2.0 clang, greedy register allocator, ``profiles/r02_hipcc_iterative_ilp_crash.txt``)."""
     import re
 
-    m = re.search(r"#define MJB_SPEC_G (\d+)", source)
-    return "iterative-ilp" if m and int(m.group(1)) == 64 else None
+    forced = os.environ.get("MJB_SPEC_SCHED")                  # experiments: "iterative-ilp", "default", ...
+    if forced is not None:
+        return None if forced in ("", "default") else forced
+    g = re.search(r"#define MJB_SPEC_G (\d+)", source)
+    ne = re.search(r"nefc_max == (\d+)", source)
+    lanes, rows = (int(g.group(1)) if g else 0), (int(ne.group(1)) if ne else 0)
+    return "iterative-ilp" if lanes == 64 or rows >= 8 else None
 
 
 def _private_cache_dir() -> str:

@@ -92,8 +92,8 @@ def test_specialised_kernel_source_and_cross_compile():
 
 
 def test_spec_scheduler_rule_and_private_cache(tmp_path, monkeypatch):
-    """VERDICT r1 #7 / ADVICE r1: the scheduler of the specialised kernel follows a stated rule (iterative ILP only for
-    one-wave-per-environment kernels; ROCm 7.2.0's clang crashes with it on the packed BASE_XML kernel,
+    """VERDICT r1 #7 / ADVICE r1: the scheduler of the specialised kernel follows a stated rule (iterative ILP for every model
+    with a constraint-row cap >= 8 or one wave per environment; ROCm 7.2.0's clang crashes with it on the degenerate BASE_XML kernel,
     profiles/r02_hipcc_iterative_ilp_crash.txt), and the fallback cache of a read-only install is private."""
     import stat
 
@@ -103,7 +103,9 @@ def test_spec_scheduler_rule_and_private_cache(tmp_path, monkeypatch):
     from mujoco_template_amd._capi import DeviceModel, compile_spec, spec_scheduler
     from tests.conftest import BASE_XML, MODELS
 
-    assert spec_scheduler(DeviceModel(mjcf.compile_xml_path(MODELS["humanoid"])).spec_source()) == "iterative-ilp"
+    for name in ("humanoid", "drone2", "cartpole"):               # models with real constraint rows: the scheduler that was measured to pay
+        assert spec_scheduler(DeviceModel(mjcf.compile_xml_path(MODELS[name])).spec_source()) == "iterative-ilp"
+    assert spec_scheduler(DeviceModel(mjcf.compile_xml_path(MODELS["pendulum"])).spec_source()) is None     # 2 rows at most: tiny kernel
     base_src = DeviceModel(mjcf.compile_xml_string(BASE_XML)).spec_source()
     assert "#define MJB_SPEC_G 8" in base_src and spec_scheduler(base_src) is None
     assert os.path.exists(compile_spec(base_src))                 # the crashing case compiles under the rule (cross-compile only)
