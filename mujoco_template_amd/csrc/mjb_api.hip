@@ -304,7 +304,7 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
 // -9 % at 100, humanoid B = 4096).  Chunk length ~ sqrt(steps)/2: per-chunk cost (state through memory, one ticket) ~2 us against
 // a tail of half a chunk.  The priority hand-over (StepArgs::fair_bit) matters where the launch waits for its slowest wave.
 static void choose_schedule(mjbData* d, StepArgs& a) {
-  a.chunk_steps = 0; a.fair_bit = 0; a.nblk = 0; a.grid_blocks = 0;
+  a.chunk_steps = 0; a.fair_bit = 0; a.nblk = 0; a.grid_blocks = 0; a.nuniform = 0; a.nchunk = 0;
   if (a.mode != 0) return;
   if (d->sched_chunk == -1) {
     const char* e1 = std::getenv("MJB_CHUNK_STEPS"); const char* e2 = std::getenv("MJB_FAIR_BIT");
@@ -328,9 +328,11 @@ static void choose_schedule(mjbData* d, StepArgs& a) {
     return;
   }
   if (d->step_slots > 0 && nblk > d->step_slots && a.nstep >= 4) {
-    // launch time ~ T0 + switches x (cost of a switch ~ 2.7 us: hand-over out, one ticket, hand-over in) + half a chunk of tail
-    // -> c ~ sqrt(0.45 N): 3 at N = 20, 7 at N = 100 (measured optimum 3 and 6..8: profiles/r02_schedule.log)
-    int c = (int)std::lround(std::sqrt(0.45 * (double)a.nstep));
+    // uniform chunks of c steps, then a guided taper (every further chunk = half of what is left, chunk_plan): the tail of the launch
+    // is half of the LAST chunk (one step), so c only trades switches (~2.7 us each: hand-over out, one ticket, hand-over in)
+    // against how early imbalance starts to be evened out.  c ~ sqrt(3 N): 8 at N = 20, 17 at N = 100 (measured flat optimum
+    // 6..12 and 12..16, profiles/r02_schedule.log), at most 32
+    int c = (int)std::lround(std::sqrt(3.0 * (double)a.nstep));
     a.chunk_steps = c < 1 ? 1 : (c > 32 ? 32 : c);
   }
   if (std::getenv("MJB_SCHED_DEBUG")) std::fprintf(stderr, "[mjb] schedule: blocks %ld, resident slots %ld, steps %d -> chunk_steps %d, fair_bit %d\n", nblk, d->step_slots, a.nstep, a.chunk_steps, a.fair_bit);
@@ -343,8 +345,9 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
   StepArgs a = a_in;
   choose_schedule(d, a);
   if (a.chunk_steps > 0) {
-    if (d->dtype != MJB_F32 || (long)(a.nstep / a.chunk_steps) >= (1L << 20) - 2) a.chunk_steps = 0;     // hand-over words are (fp32, tag) pairs; 20 bits of chunk index
+    if (d->dtype != MJB_F32 || a.nstep >= (1 << 20) - 2) a.chunk_steps = 0;     // hand-over words are (fp32, tag) pairs; 20 bits of step index in the tag
   }
+  if (a.chunk_steps > 0) chunk_plan_counts(a.nstep, a.chunk_steps, a.nuniform, a.nchunk);
   if (a.mode == 0) {
     const int epb = 64 / d->G;
     d->last_sched[0] = a.nstep; d->last_sched[1] = (d->batch + epb - 1) / epb; d->last_sched[2] = (int)(d->step_slots > 0 ? d->step_slots : 0);
@@ -355,8 +358,7 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
     a.tagbase = (d->launch_seq & 0xFFFu) << 20;
     // the ticket counter is never reset on the hot path: every launched workgroup draws tickets until one is past the end, so a
     // launch advances the counter by exactly (tickets + workgroups) and the next launch starts from there (32-bit: rewound long before it wraps)
-    const unsigned nchunk = ((unsigned)a.nstep + (unsigned)a.chunk_steps - 1) / (unsigned)a.chunk_steps;
-    const unsigned long long adv = (unsigned long long)a.nblk * nchunk + (unsigned long long)a.grid_blocks;
+    const unsigned long long adv = (unsigned long long)a.nblk * (unsigned)a.nchunk + (unsigned long long)a.grid_blocks;
     if (d->ticket_next + adv > 0xF0000000ull) { HIPCHK(hipMemsetAsync(d->df.sched, 0, sizeof(unsigned), d->stream)); d->ticket_next = 0; }
     a.ticket_base = (unsigned)d->ticket_next;
     d->ticket_next += adv;

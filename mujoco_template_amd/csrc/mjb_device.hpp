@@ -2398,8 +2398,8 @@ template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c
 // ---------------------------------------------------------------------------
 // Hand-over of an environment between the chunks of ONE launch (ticket mode of k_step, mjb_kernels.hpp): the wave that ends chunk
 // k - 1 and the wave that starts chunk k may sit on different XCDs, so the words travel as 64-bit (value, tag) pairs written and
-// read with agent-scope relaxed atomics (single-copy atomic, coherent across the XCDs' L2s): tag = tagbase + chunk index is unique
-// per launch and chunk, every word validates itself, no flag, no fence, and the producer never waits for its stores.
+// read with agent-scope relaxed atomics (single-copy atomic, coherent across the XCDs' L2s): tag = tagbase + step index is unique
+// per launch and hand-over, every word validates itself, no flag, no fence, and the producer never waits for its stores.
 //   xfer[env, j],  j over  qpos | qvel | qacc_warmstart | qacc | time (lo, hi)          (ctrl is either regenerated every step or
 //   constant over the launch and read from its array)
 #ifndef MJB_HOST_EMU
@@ -2539,8 +2539,8 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
   }
 #if !defined(MJB_HOST_EMU) && !defined(MJB_NO_XFER)
   if constexpr (sizeof(T) == 4 && sizeof(TS) == 4) {
-    // chunk k ends at s_end = (k + 1) chunk_steps: its hand-over carries tag k + 1
-    const unsigned tag_out = (a.mode == 0 && a.chunk_steps > 0 && s_end < a.nstep) ? a.tagbase + (unsigned)s_end / (unsigned)a.chunk_steps : 0u;
+    // the hand-over made at step s_end carries tag tagbase + s_end
+    const unsigned tag_out = (a.mode == 0 && a.chunk_steps > 0 && s_end < a.nstep) ? a.tagbase + (unsigned)s_end : 0u;
     if (tag_out != 0) {                                        // hand the environment to whoever draws its next chunk
       unsigned long long* x = d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2);
       for (int i = lane; i < nq; i += G) xfer_st(x + i, __float_as_uint(w[L.qpos + i]), tag_out);

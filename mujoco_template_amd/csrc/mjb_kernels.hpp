@@ -17,8 +17,8 @@ namespace mjb {
 //  * tickets (chunk_steps > 0, fp32 only): with more blocks than the chip holds, the static map runs in "rounds" and every round
 //    waits for its slowest environment (a Newton iteration costs ~5.5 us and their number per step varies 0..8: over 20 steps the wave
 //    durations spread 0.5..1.35 ms around 1.0, profiles/r02_wave_timeline.log).  Here only the resident workgroups are launched; they
-//    stay for the whole launch and draw tickets from one atomic counter: ticket t = chunk (t / nblk) of block (t % nblk), a chunk =
-//    chunk_steps consecutive steps.  Between its chunks an environment travels through the tagged hand-over buffer (env_run), which
+//    stay for the whole launch and draw tickets from one atomic counter: ticket t = chunk (t / nblk) of block (t % nblk); the chunks
+//    are chunk_steps consecutive steps, then ever shorter ones towards the end of the launch (chunk_plan, mjb_types.hpp).  Between its chunks an environment travels through the tagged hand-over buffer (env_run), which
 //    is also what orders the chunks: a wave that draws chunk k finds the words tagged k or re-reads until it does.  Tickets are
 //    handed out in order, so the wave it waits for holds a SMALLER ticket and never waits for this one: no cycle.
 //
@@ -59,15 +59,15 @@ MJB_DEV void k_step_body() {
     int s0 = 0, s1 = a.nstep;
     unsigned tag_in = 0;
     if (tickets) {
-      const unsigned nblk = (unsigned)a.nblk, cs = (unsigned)a.chunk_steps, nchunk = ((unsigned)a.nstep + cs - 1) / cs;
+      const unsigned nblk = (unsigned)a.nblk, nchunk = (unsigned)a.nchunk;
       unsigned t = 0;
       if (threadIdx.x == 0) t = atomicAdd(d.sched, 1u);
       t = (unsigned)__builtin_amdgcn_readfirstlane((int)t) - a.ticket_base;
       if (t >= nblk * nchunk) break;
       const unsigned k = t / nblk;
       blk = t - k * nblk;
-      s0 = (int)(k * cs); s1 = k + 1 == nchunk ? a.nstep : (int)((k + 1) * cs);
-      tag_in = k > 0 ? a.tagbase + k : 0u;
+      chunk_plan(a.nstep, a.chunk_steps, a.nuniform, (int)k, s0, s1);
+      tag_in = s0 > 0 ? a.tagbase + (unsigned)s0 : 0u;         // the hand-over made at step s0 carries tag tagbase + s0
     }
     const int env = (int)blk * (64 / G) + sub;
     if (env < d.batch) env_run<T, TS, G>(mp, lp, d, kp->dbg, a, kp->obs, kp->obs_out, w, wi, env, lane, s0, s1, tag_in, MJB_TLACC);

@@ -147,10 +147,34 @@ struct StepArgs {
   int fb_nsteps, fb_env_stride;
   int fair_bit;          // >0: alternate the issue priority of a SIMD's waves by this bit of the 100 MHz clock (env_run); 0 = leave the hardware's age order
   unsigned ticket_base;  // ticket mode: value of d.sched[0] when this launch starts (the counter is not reset between launches)
-  unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ chunk index), unique among the launches that could still be in the buffer
+  unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ the step index at which the hand-over happens), unique among the launches that could still be in the buffer
   int nblk, grid_blocks; // ticket mode: environment blocks of the batch; workgroups launched (the resident ones)
-  int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of this many steps) tickets from d.sched (mjb_kernels.hpp)
+  int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of steps) tickets from d.sched (mjb_kernels.hpp)
+  int nuniform, nchunk;  // ticket mode, the chunk plan of an environment's nstep steps: `nuniform` chunks of chunk_steps steps, then every
+                         // further chunk takes HALF of what is left (guided taper down to single steps: the launch's tail is half of the
+                         // LAST chunk); nchunk = all chunks.  chunk_plan() below is the one definition, used by host and device.
 };
+
+// Chunk k of the plan (nstep, chunk_steps, nuniform): steps [s0, s1).  Host and device.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline void chunk_plan(int nstep, int chunk_steps, int nuniform, int k, int& s0, int& s1) {
+  if (k < nuniform) { s0 = k * chunk_steps; s1 = s0 + chunk_steps; return; }
+  int at = nuniform * chunk_steps;
+  for (int j = nuniform;; j++) {
+    const int rem = nstep - at, sz = rem > 1 ? (rem + 1) / 2 : rem;
+    if (j == k) { s0 = at; s1 = at + sz; return; }
+    at += sz;
+  }
+}
+// the plan for a launch of nstep steps with uniform chunks of c: nuniform, nchunk
+inline void chunk_plan_counts(int nstep, int c, int& nuniform, int& nchunk) {
+  nuniform = nstep >= 2 * c ? (nstep - c) / c : 0;
+  int rem = nstep - nuniform * c, nt = 0;
+  while (rem > 0) { rem -= rem > 1 ? (rem + 1) / 2 : rem; nt++; }
+  nchunk = nuniform + nt;
+}
 
 // References to launch arguments as the device code takes them: objects in the constant address space (the kernarg segment), so
 // that every field read is a scalar load that can be redone where it is needed instead of a value kept live (k_step_body).
