@@ -262,6 +262,7 @@ def compile_spec(source: str, *, force: bool = False) -> str:
             fh.write(source)
     except OSError as exc:
         raise TemplateError(f"cannot write the specialised kernel source: {exc}") from exc
+    # same floating-point flags as csrc/Makefile (contraction per source expression, correctly rounded division / sqrt): bitwise equal to the generic kernel
     # -disable-machine-licm: the step kernel is one persistent loop around the whole forward pipeline; hoisting the body's literal
     # constants out of it costs more registers than the kernel has (csrc/Makefile, STEPFLAGS)
     base = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", "-mllvm", "-disable-machine-licm"]
