@@ -272,6 +272,60 @@ void choose_caps(const HostModel& h, int dtype, int lanes, int nconmax, int nefc
 }
 int auto_lanes(const HostModel& h, int lanes) { return lanes == 0 ? (h.nv <= 4 ? 8 : (h.nv <= 16 ? 16 : 64)) : lanes; }
 
+// The model itself as `__constant__` data of the specialised translation unit (MJB_SPEC_BAKED, mjb_device.hpp): fill_dev_model runs
+// against an allocator that EMITS every table as a C array and hands out recognisable tokens instead of addresses; the filled
+// DevModel<float> is then written out word by word as a struct of the same layout (pointer words -> the emitted arrays, everything
+// else -> the bit pattern), so the image cannot fall out of step with fill_dev_model or with the struct's member list.
+struct EmitAlloc {
+  std::string text;            // one `static const __constant__` array per table: its own symbol, so a lane-indexed read is
+  int n = 0;                   // global_load(table address + lane offset) with no further address arithmetic
+  static constexpr unsigned long long TOKEN = 0x7E57AB1Eull << 32;
+  template <typename X, typename F> const X* emit(const std::vector<X>& v, const char* ctype, F fmt) {
+    text += std::string("static const __constant__ ") + ctype + " mjb_tab_" + std::to_string(n) + "[] = {";
+    if (v.empty()) text += "0";
+    for (size_t i = 0; i < v.size(); i++) { if (i) text += (i % 16 == 0 ? ",\n " : ","); text += fmt(v[i]); }
+    text += "};\n";
+    return (const X*)(uintptr_t)(TOKEN + (unsigned long long)(n++) * 16ull + 16ull);
+  }
+  const float* putf(const std::vector<float>& v) {
+    return emit(v, "float", [](float x) { char b[48]; std::snprintf(b, sizeof(b), "%af", (double)x); return std::string(b); });
+  }
+  const int* puti(const std::vector<int>& v) { return emit(v, "int", [](int x) { return std::to_string(x); }); }
+  const unsigned long long* putu(const std::vector<unsigned long long>& v) {
+    return emit(v, "unsigned long long", [](unsigned long long x) { char b[40]; std::snprintf(b, sizeof(b), "0x%llxull", x); return std::string(b); });
+  }
+};
+
+std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max) {
+  static_assert(sizeof(DevModel<float>) % 8 == 0, "DevModel<float> is written out in 8-byte words");
+  EmitAlloc ea;
+  DevModel<float> m;
+  fill_dev_model<float>(h, ea, ncon_max, nefc_max, m);
+  const size_t nw = sizeof(m) / 8;
+  std::vector<unsigned long long> wv(nw);
+  std::memcpy(wv.data(), (const void*)&m, sizeof(m));
+  std::string decl = "struct MjbBakedModel {", init = "static const __constant__ MjbBakedModel mjb_baked_model = {";
+  for (size_t i = 0; i < nw; i++) {
+    const unsigned long long v = wv[i];
+    if ((v >> 32) == (EmitAlloc::TOKEN >> 32)) {
+      decl += " const void MJB_CONST* p" + std::to_string(i) + ";";
+      init += " (const void MJB_CONST*)mjb_tab_" + std::to_string((v - EmitAlloc::TOKEN) / 16 - 1) + ",";
+    } else {
+      char b[64];
+      decl += " unsigned a" + std::to_string(i) + ", b" + std::to_string(i) + ";";
+      std::snprintf(b, sizeof(b), " 0x%xu, 0x%xu,", (unsigned)(v & 0xffffffffull), (unsigned)(v >> 32));
+      init += b;
+    }
+    if (i % 8 == 7) init += "\n ";
+  }
+  decl += " };\n"; init += " };\n";
+  std::string s = "#include \"mjb_types.hpp\"\n// the model as constant data of this translation unit (tables, then the DevModel<float> image)\n";
+  s += ea.text + decl + init;
+  s += "static_assert(sizeof(MjbBakedModel) == sizeof(mjb::DevModel<float>), \"baked model image\");\n";
+  s += "#define MJB_SPEC_BAKED (*(const mjb::DevModel<float> MJB_CONST*)&mjb_baked_model)\n";
+  return s;
+}
+
 // Translation unit of the specialised fp32 step kernel of one compiled model: the structural sizes of DevModel (never the
 // run-time options: disableactuator, iterations, tolerance) and every LDS layout offset become __builtin_assume()s.
 std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, int nefc_max) {
@@ -294,7 +348,9 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
   SL(efc_force); SL(efc_KBI); SL(Ma); SL(grad); SL(search); SL(Mv); SL(tmp); SL(cholcol); SL(rk); SL(nT); SL(i_efc_type); SL(i_efc_id);
   SL(i_con_pair); SL(i_scal); SL(nI); SL(bytes);
 #undef SL
-  s += "\n#include \"mjb_kernels.hpp\"\n";
+  s += "\n";
+  if (!std::getenv("MJB_SPEC_NO_BAKE")) s += baked_model_source(h, ncon_max, nefc_max);
+  s += "#include \"mjb_kernels.hpp\"\n";
   return s;
 }
 

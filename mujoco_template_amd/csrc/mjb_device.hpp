@@ -503,13 +503,23 @@ MJB_DEV void tile_factor(MRef m, const T* M, T* W, T* dinv, T* col, const T* J, 
 #ifndef MJB_SPEC_ASSUME_LAY
 #define MJB_SPEC_ASSUME_LAY(L)
 #endif
+// Baked model (specialised translation units, mjb_model_spec_source): MJB_SPEC_BAKED names a `__constant__` image of the model's
+// DevModel<float> whose table pointers point at `__constant__` arrays of the SAME translation unit, so a table read is ONE access at
+// a link-time address (no pointer hop through the device copy of DevModel) and reads with compile-time indices fold to literals.
+// The run-time options (disableactuator, iterations, tolerance) are never baked: MJB_OPT reads them from the device copy.
+#if defined(MJB_SPEC_BAKED) && !defined(MJB_HOST_EMU)
+#define MJB_MODEL_OF(p) MJB_SPEC_BAKED
+#else
+#define MJB_MODEL_OF(p) (*(p))
+#endif
+#define MJB_OPT(c, f) ((*(c).mp).f)
 #ifdef MJB_HOST_EMU
 #define MJB_ENV(c) ModelRef<T> m = *(c).mp; LayRef L = *(c).lp
 #else
 #define MJB_ENV(c)                                     \
   auto mp_ = (c).mp; auto lp_ = (c).lp;                \
   asm volatile("" : "+s"(mp_), "+s"(lp_));             \
-  ModelRef<T> m = *mp_; LayRef L = *lp_;               \
+  ModelRef<T> m = MJB_MODEL_OF(mp_); LayRef L = *lp_;  \
   MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
 #endif
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
@@ -1269,7 +1279,7 @@ template <typename T, int G> MJB_DEV void com_pos(Ctx<T>& c) {
 
 // Jacobian column of dof i for a world point attached to body b (zero if i does not move b)
 template <typename T> MJB_DEV void jac_col(const Ctx<T>& c, int b, int i, const T* point, T* jp, T* jr) {
-  ModelRef<T> m = *c.mp;
+  ModelRef<T> m = MJB_MODEL_OF(c.mp);
   jp[0] = jp[1] = jp[2] = 0;
   if (jr) { jr[0] = jr[1] = jr[2] = 0; }
   if (!((m.body_dofmask[b] >> i) & 1ull)) return;
@@ -1890,7 +1900,7 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
   for (int a = lane; a < m.nu; a += G) {
     int grp = m.actuator_group[a];
     T force = 0;
-    if (!(grp >= 0 && grp < 31 && ((m.disableactuator >> grp) & 1))) {
+    if (!(grp >= 0 && grp < 31 && ((MJB_OPT(c, disableactuator) >> grp) & 1))) {
       T u = ctrl[a];
       if (m.actuator_ctrllimited[a]) u = t_min(t_max(u, m.actuator_ctrlrange[2 * a]), m.actuator_ctrlrange[2 * a + 1]);
       force = m.actuator_gainprm[3 * a] * u;
@@ -2038,9 +2048,9 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   }
   gsync<G>();
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
-  for (int iter = 0; iter < m.iterations; iter++) {
+  for (int iter = 0; iter < MJB_OPT(c, iterations); iter++) {
     MJB_STAMP(c, PH_SOLVE);
-    const T gtol = m.tolerance / scale;
+    const T gtol = MJB_OPT(c, tolerance) / scale;
     T gn = newton_direction<T, G>(c, iter == 0, gtol * gtol);
     MJB_STAMP(c, PH_SOL_DIR);
     if (gn < gtol * gtol) break;
@@ -2116,7 +2126,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     cost = gsum<T, G>(part);
     gsync<G>();
     c.niter = iter + 1;
-    if (scale * (old - cost) < m.tolerance) break;
+    if (scale * (old - cost) < MJB_OPT(c, tolerance)) break;
   }
   if (jt_split<T, G>(nv)) {
     T jf = jt_dot<T, G>(J, force, nefc, nv, lane);
@@ -2129,7 +2139,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
 
 // A12 sensors of the last forward pass: jointpos, gyro, framequat, accelerometer (lanes over sensors)
 template <typename T, typename TS, int G> MJB_DEV void sensors(const Ctx<T>& c, TS* dst) {
-  ModelRef<T> m = *c.mp; LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
+  ModelRef<T> m = MJB_MODEL_OF(c.mp); LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
   for (int s = lane; s < m.nsensor; s += G) {
     TS* out = dst + m.sensor_adr[s];
     int id = m.sensor_objid[s], st = m.sensor_type[s];
@@ -2375,7 +2385,7 @@ template <typename T, int G> MJB_DEV void reset_state(Ctx<T>& c) {
 // flat observation (keys in sorted order, reference observations.py:171-174):
 // bodies_pos, ctrl, geoms_pos, qpos, qvel, sensordata, sites_pos, subtree_com, time
 template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c, ObsRef s, double time, TS* out) {
-  ModelRef<T> m = *c.mp; LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
+  ModelRef<T> m = MJB_MODEL_OF(c.mp); LayRef L = *c.lp; const T* w = c.w; const int lane = c.lane;
   int o = 0;
   const T* bsrc = (s.flags & 64) ? w + L.xipos : w + L.xpos;
   for (int i = lane; i < 3 * s.nbody; i += G) out[o + i] = (TS)bsrc[3 * s.body_ids[i / 3] + i % 3];
@@ -2417,7 +2427,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
                      ObsRef obs, TS* obs_out, T* w, int* wi, int env, int lane, int s_begin, int s_end, unsigned tag_in,
                      unsigned long long* tlacc = nullptr) {
   Ctx<T> c(mp, lp, w, wi, lane);
-  ModelRef<T> m = *mp; LayRef L = *lp;
+  ModelRef<T> m = MJB_MODEL_OF(mp); LayRef L = *lp;
   MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
   const int nq = m.nq, nv = m.nv, nu = m.nu;
   double time;
