@@ -125,6 +125,12 @@ long mjb_model_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int n
 long mjb_spec_source(mjbData* d, char* buf, long cap);
 int mjb_spec_load(mjbData* d, const void* code_object, long nbytes);
 int mjb_spec_unload(mjbData* d);
+/* The same for the float64 finite-difference kernel behind mjb_transition_fd (k_fd<double, TS, G> of this data object: float64 layout,
+ * model baked in as float64 constants): source -> `hipcc --genco` -> mjb_fd_spec_load; results bitwise those of the generic kernel. */
+long mjb_model_fd_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int nefcmax, char* buf, long cap);   /* without a data object (build step) */
+long mjb_fd_spec_source(mjbData* d, char* buf, long cap);
+int mjb_fd_spec_load(mjbData* d, const void* code_object, long nbytes);
+int mjb_fd_spec_unload(mjbData* d);
 
 /* mj_resetData / mj_resetDataKeyframe (reference model.py:59-71); key < 0 = qpos0 */
 int mjb_reset(mjbData* d, int key);

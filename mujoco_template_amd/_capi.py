@@ -74,6 +74,12 @@ def load_library() -> ctypes.CDLL:
     L.mjb_spec_source.restype = cl
     L.mjb_spec_load.argtypes = [vp, ctypes.c_char_p, cl]
     L.mjb_spec_unload.argtypes = [vp]
+    L.mjb_model_fd_spec_source.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char_p, cl]
+    L.mjb_model_fd_spec_source.restype = cl
+    L.mjb_fd_spec_source.argtypes = [vp, ctypes.c_char_p, cl]
+    L.mjb_fd_spec_source.restype = cl
+    L.mjb_fd_spec_load.argtypes = [vp, ctypes.c_char_p, cl]
+    L.mjb_fd_spec_unload.argtypes = [vp]
     L.mjb_inverse.argtypes = [vp]
     L.mjb_step.argtypes = [vp, ci]
     L.mjb_rollout.argtypes = [vp, ci, ci, cu, cu, cd, vp, vp, ci]
@@ -118,7 +124,7 @@ def load_library() -> ctypes.CDLL:
     L.mjb_step_host.argtypes = [vp, ci, ci]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
-                 "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
+                 "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_fd_spec_load", "mjb_fd_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get", "mjb_model_field", "mjb_model_field_at", "mjb_model_save",
                  "mjb_model_load", "mjb_model_load_xml", "mjb_model_load_xml_string", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
                  "mjb_step_host"):
@@ -267,6 +273,8 @@ def compile_spec(source: str, *, force: bool = False) -> str:
     # constants out of it costs more registers than the kernel has (csrc/Makefile, STEPFLAGS)
     base = [hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-ffp-contract=on", "-mllvm", "-disable-machine-licm"]
     tail = [*extra, "-I", _CSRC, "-o", tmp, src]
+    if "#define MJB_SPEC_KERNEL 2" in source:                   # the finite-difference kernel has no persistent loop around its body
+        base = [x for x in base if x not in ("-mllvm", "-disable-machine-licm")]
     attempts = [[*base, "-mllvm", f"-amdgpu-sched-strategy={sched}", *tail], [*base, *tail]] if sched else [[*base, *tail]]
     err = ""
     for k, cmd in enumerate(attempts):
@@ -405,6 +413,10 @@ class DeviceModel:
         """Translation unit of the specialised fp32 step kernel for these creation arguments (no GPU needed)."""
         return _source_from(load_library().mjb_model_spec_source, self.ptr, MJB_F32, int(lanes), int(nconmax), int(nefcmax))
 
+    def fd_spec_source(self, *, dtype: str = "float32", lanes: int = 0, nconmax: int = 0, nefcmax: int = 0) -> str:
+        """Translation unit of the specialised float64 finite-difference kernel for these creation arguments (no GPU needed)."""
+        return _source_from(load_library().mjb_model_fd_spec_source, self.ptr, MJB_F32 if dtype == "float32" else MJB_F64, int(lanes), int(nconmax), int(nefcmax))
+
     def __del__(self):
         try:
             if self.ptr:
@@ -436,6 +448,9 @@ class BatchSim:
         # per-model specialised fp32 kernel: on by default (MJB_SPECIALIZE=0 turns the default off); an explicit True raises
         # if it cannot be built, the default falls back to the generic kernel with one warning
         self.specialized = False
+        self.fd_specialized = False
+        self._fd_spec_tried = False
+        self._spec_policy = specialize                             # None: default (on unless MJB_SPECIALIZE=0); True: required; False: never
         want = specialize if specialize is not None else (dtype == "float32" and os.environ.get("MJB_SPECIALIZE", "1") != "0")
         if want:
             try:
@@ -466,6 +481,20 @@ class BatchSim:
     def unspecialize(self) -> None:
         _check(load_library().mjb_spec_unload(self.ptr))
         self.specialized = False
+
+    def fd_spec_source(self) -> str:
+        return _source_from(load_library().mjb_fd_spec_source, self.ptr)
+
+    def specialize_fd(self) -> None:
+        """The float64 finite-difference kernel behind ``transition_fd`` specialised to this model (sizes, float64 LDS layout,
+        the model baked in as constants); identical arithmetic to the generic kernel.  Done lazily by the first ``transition_fd``."""
+        image = _read_private(compile_spec(self.fd_spec_source()))
+        _check(load_library().mjb_fd_spec_load(self.ptr, image, len(image)))
+        self.fd_specialized = True
+
+    def unspecialize_fd(self) -> None:
+        _check(load_library().mjb_fd_spec_unload(self.ptr))
+        self.fd_specialized = False
 
     # -- plumbing -----------------------------------------------------------------
     def set_stream(self, stream_handle: int) -> None:
@@ -592,6 +621,18 @@ class BatchSim:
         """(A [batch, 2nv, 2nv], B [batch, 2nv, nu]).  ``copy=False`` returns views of the library's pinned result blocks (no
         16 MB host copy at humanoid batch 512), valid until the next ``transition_fd`` on this object."""
         m = self.model.compiled
+        if not self._fd_spec_tried:                                # first call: the per-model specialised kernel, by the same policy as the step kernel
+            self._fd_spec_tried = True
+            want = self._spec_policy if self._spec_policy is not None else os.environ.get("MJB_SPECIALIZE", "1") != "0"
+            if want:
+                try:
+                    self.specialize_fd()
+                except TemplateError as exc:
+                    if self._spec_policy:
+                        raise
+                    import warnings
+
+                    warnings.warn(f"finite-difference kernel not specialised, using the generic kernel: {exc}", RuntimeWarning, stacklevel=2)
         pa, pb = ctypes.POINTER(ctypes.c_double)(), ctypes.POINTER(ctypes.c_double)()
         _check(load_library().mjb_transition_fd_pinned(self.ptr, float(eps), int(bool(centered)), ctypes.byref(pa), ctypes.byref(pb)))
         A = np.ctypeslib.as_array(pa, shape=(self.batch, 2 * m.nv, 2 * m.nv))

@@ -92,6 +92,8 @@ struct mjbData {
   // per-model specialised fp32 step kernel (mjb_spec_load); null = generic kernel
   hipModule_t spec_mod = nullptr;
   hipFunction_t spec_fn = nullptr;
+  hipModule_t fd_spec_mod = nullptr;       // per-model specialised float64 finite-difference kernel (mjb_fd_spec_load); null = generic k_fd
+  hipFunction_t fd_spec_fn = nullptr;
   // work scheduling of k_step (launch()): resident workgroups of the kernel in use on this device; < 0 = not yet queried
   long step_slots = -1;
   int sched_chunk = -1, fair_bit = -1;     // experiment overrides (MJB_CHUNK_STEPS, MJB_FAIR_BIT); -1 = policy below
@@ -290,17 +292,22 @@ struct EmitAlloc {
   const float* putf(const std::vector<float>& v) {
     return emit(v, "float", [](float x) { char b[48]; std::snprintf(b, sizeof(b), "%af", (double)x); return std::string(b); });
   }
+  const double* putf(const std::vector<double>& v) {
+    return emit(v, "double", [](double x) { char b[48]; std::snprintf(b, sizeof(b), "%a", x); return std::string(b); });
+  }
   const int* puti(const std::vector<int>& v) { return emit(v, "int", [](int x) { return std::to_string(x); }); }
   const unsigned long long* putu(const std::vector<unsigned long long>& v) {
     return emit(v, "unsigned long long", [](unsigned long long x) { char b[40]; std::snprintf(b, sizeof(b), "0x%llxull", x); return std::string(b); });
   }
 };
 
+template <typename T>
 std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max) {
-  static_assert(sizeof(DevModel<float>) % 8 == 0, "DevModel<float> is written out in 8-byte words");
+  static_assert(sizeof(DevModel<T>) % 8 == 0, "DevModel<T> is written out in 8-byte words");
+  const char* tname = sizeof(T) == 4 ? "float" : "double";
   EmitAlloc ea;
-  DevModel<float> m;
-  fill_dev_model<float>(h, ea, ncon_max, nefc_max, m);
+  DevModel<T> m;
+  fill_dev_model<T>(h, ea, ncon_max, nefc_max, m);
   const size_t nw = sizeof(m) / 8;
   std::vector<unsigned long long> wv(nw);
   std::memcpy(wv.data(), (const void*)&m, sizeof(m));
@@ -319,18 +326,20 @@ std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max) {
     if (i % 8 == 7) init += "\n ";
   }
   decl += " };\n"; init += " };\n";
-  std::string s = "#include \"mjb_types.hpp\"\n// the model as constant data of this translation unit (tables, then the DevModel<float> image)\n";
+  std::string s = "#include \"mjb_types.hpp\"\n// the model as constant data of this translation unit (tables, then the DevModel image)\n";
   s += ea.text + decl + init;
-  s += "static_assert(sizeof(MjbBakedModel) == sizeof(mjb::DevModel<float>), \"baked model image\");\n";
-  s += "#define MJB_SPEC_BAKED (*(const mjb::DevModel<float> MJB_CONST*)&mjb_baked_model)\n";
+  s += std::string("static_assert(sizeof(MjbBakedModel) == sizeof(mjb::DevModel<") + tname + ">), \"baked model image\");\n";
+  s += std::string("#define MJB_SPEC_BAKED (*(const mjb::DevModel<") + tname + "> MJB_CONST*)&mjb_baked_model)\n";
   return s;
 }
 
 // Translation unit of the specialised fp32 step kernel of one compiled model: the structural sizes of DevModel (never the
 // run-time options: disableactuator, iterations, tolerance) and every LDS layout offset become __builtin_assume()s.
-std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, int nefc_max) {
-  std::string s = "// generated by mjb_model_spec_source(): size- and layout-specialised k_step<float, float, G> of ONE compiled model\n";
-  s += "#define MJB_SPEC_KERNEL 1\n#define MJB_SPEC_G " + std::to_string(G) + "\n#define MJB_SPEC_ASSUME(m)";
+// kind 1: the fp32 step kernel (L = the fp32 layout); kind 2: the float64 finite-difference kernel k_fd<double, ts, G> (L = the float64 layout)
+std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, int nefc_max, int kind = 1, const char* ts = "float") {
+  std::string s = kind == 1 ? "// generated by mjb_model_spec_source(): size- and layout-specialised k_step<float, float, G> of ONE compiled model\n"
+                            : "// generated by mjb_fd_spec_source(): size- and layout-specialised k_fd<double, TS, G> of ONE compiled model\n";
+  s += "#define MJB_SPEC_KERNEL " + std::to_string(kind) + "\n#define MJB_SPEC_TS " + ts + "\n#define MJB_SPEC_G " + std::to_string(G) + "\n#define MJB_SPEC_ASSUME(m)";
   auto A = [&](const char* obj, const char* f, long v) { s += std::string(" __builtin_assume((") + obj + ")." + f + " == " + std::to_string(v) + ");"; };
 #define SM(f, v) A("m", #f, (long)(v))
   SM(nq, h.nq); SM(nv, h.nv); SM(nu, h.nu); SM(nbody, h.nbody); SM(njnt, h.njnt); SM(ngeom, h.ngeom); SM(nsite, h.nsite);
@@ -349,7 +358,7 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
   SL(i_con_pair); SL(i_scal); SL(nI); SL(bytes);
 #undef SL
   s += "\n";
-  if (!std::getenv("MJB_SPEC_NO_BAKE")) s += baked_model_source(h, ncon_max, nefc_max);
+  if (!std::getenv("MJB_SPEC_NO_BAKE")) s += kind == 1 ? baked_model_source<float>(h, ncon_max, nefc_max) : baked_model_source<double>(h, ncon_max, nefc_max);
   s += "#include \"mjb_kernels.hpp\"\n";
   return s;
 }
@@ -540,6 +549,7 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
 
 void mjb_data_free(mjbData* d) {
   if (d && d->spec_mod) { hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; }
+  if (d && d->fd_spec_mod) { hipModuleUnload(d->fd_spec_mod); d->fd_spec_mod = nullptr; d->fd_spec_fn = nullptr; }
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : d->owned) (void)hipFree(p);
@@ -652,6 +662,24 @@ long mjb_model_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int n
   return (long)src.size();
 }
 
+// the finite-difference kernel's translation unit for the creation arguments a data object of this model would get (no GPU needed:
+// the same caps, float64 layout and lane-group width mjb_data_create derives)
+long mjb_model_fd_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int nefcmax, char* buf, long cap) {
+  if (!m) { fail(MJB_ERR_ARG, "model is NULL"); return -1; }
+  if (dtype != MJB_F32 && dtype != MJB_F64) { fail(MJB_ERR_ARG, "dtype must be MJB_F32 or MJB_F64"); return -1; }
+  const HostModel& h = m->h;
+  lanes = auto_lanes(h, lanes);
+  if (lanes != 8 && lanes != 16 && lanes != 64) { fail(MJB_ERR_ARG, "lanes must be 8, 16 or 64"); return -1; }
+  int nc, ne;
+  choose_caps(h, dtype, lanes, nconmax, nefcmax, nc, ne);
+  const Lay Ld = make_layout(h, nc, ne, sizeof(double));
+  int gfd = lanes;
+  while (gfd < 64 && (size_t)(64 / gfd) * (size_t)Ld.bytes > 160 * 1024) gfd = gfd == 8 ? 16 : 64;
+  const std::string src = spec_source(h, Ld, gfd, nc, ne, 2, dtype == MJB_F32 ? "float" : "double");
+  if (buf && cap > (long)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+  return (long)src.size();
+}
+
 long mjb_spec_source(mjbData* d, char* buf, long cap) {
   if (!d) { fail(MJB_ERR_ARG, "data is NULL"); return -1; }
   if (d->dtype != MJB_F32) { fail(MJB_ERR_ARG, "only the float32 step kernel is specialised"); return -1; }
@@ -678,6 +706,33 @@ int mjb_spec_load(mjbData* d, const void* image, long nbytes) {
 int mjb_spec_unload(mjbData* d) {
   if (!d) return fail(MJB_ERR_ARG, "data is NULL");
   if (d->spec_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; d->step_slots = -1; }
+  return MJB_OK;
+}
+
+long mjb_fd_spec_source(mjbData* d, char* buf, long cap) {
+  if (!d) { fail(MJB_ERR_ARG, "data is NULL"); return -1; }
+  const std::string src = spec_source(d->model->h, d->Ld, d->G_fd, d->ncon_max, d->nefc_max, 2, d->dtype == MJB_F32 ? "float" : "double");
+  if (buf && cap > (long)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+  return (long)src.size();
+}
+
+int mjb_fd_spec_load(mjbData* d, const void* image, long nbytes) {
+  if (!d || !image || nbytes <= 0) return fail(MJB_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  if (d->fd_spec_mod) { hipModuleUnload(d->fd_spec_mod); d->fd_spec_mod = nullptr; d->fd_spec_fn = nullptr; }
+  hipModule_t mod; hipFunction_t fn;
+  hipError_t e = hipModuleLoadData(&mod, image);
+  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+  e = hipModuleGetFunction(&fn, mod, "mjb_k_fd_spec");
+  if (e != hipSuccess) { hipModuleUnload(mod); return fail(MJB_ERR_DEVICE, "code object has no mjb_k_fd_spec kernel"); }
+  d->fd_spec_mod = mod; d->fd_spec_fn = fn;
+  return MJB_OK;
+}
+
+int mjb_fd_spec_unload(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (d->fd_spec_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->fd_spec_mod); d->fd_spec_mod = nullptr; d->fd_spec_fn = nullptr; }
   return MJB_OK;
 }
 
@@ -875,8 +930,20 @@ static int transition_fd_impl(mjbData* d, double eps, int centered) {
     if (const char* e = std::getenv("MJB_FD_CHUNK")) chunk = std::atoi(e);        // experiments (scripts/gpu_fd_timing.py)
     else chunk = want < 1 ? 1 : (want > 8 ? 8 : (int)want);
   }
-  hipError_t e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream)
-                                     : launch_fd<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream);
+  hipError_t e;
+  if (d->fd_spec_fn) {                                          // per-model specialised kernel: same arguments, same grid as launch_fd_g
+    if (chunk < 1) chunk = 1;
+    const int epb = 64 / d->G_fd;
+    const int njob = (1 + 2 * h.nu + chunk - 1) / chunk + (2 * h.nv + chunk - 1) / chunk + 2 * h.nv;
+    const long ngroups = (long)d->batch * njob;
+    const DevModel<double>* mg = d->md_dev; const Lay* lg = d->Ld_dev;
+    DevData<float> dvf = d->df; DevData<double> dvd = d->dd;
+    int ncol_ = ncol, cv = chunk, cc = chunk; double eps_ = eps; double* yy = d->fd_y; int* vv = d->fd_valid;
+    void* args[] = {(void*)&mg, (void*)&lg, d->dtype == MJB_F32 ? (void*)&dvf : (void*)&dvd, (void*)&ncol_, (void*)&eps_, (void*)&yy, (void*)&vv, (void*)&cv, (void*)&cc};
+    e = hipModuleLaunchKernel(d->fd_spec_fn, (unsigned)((ngroups + epb - 1) / epb), 1, 1, 64, 1, 1, (unsigned)((size_t)epb * d->Ld.bytes), d->stream, args, nullptr);
+  } else
+  e = d->dtype == MJB_F32 ? launch_fd<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream)
+                          : launch_fd<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream);
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("fd launch: ") + hipGetErrorString(e));
   long nthreads = (long)B * nin;
   hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, (const DevModel<double>*)d->md_dev, d->batch, ncol, centered, eps,

@@ -97,7 +97,7 @@ template <typename T, typename TS, int G>
 __global__ __launch_bounds__(64, MJB_WPS) void k_step(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
   k_step_body<T, TS, G>();
 }
-#ifdef MJB_SPEC_KERNEL
+#if defined(MJB_SPEC_KERNEL) && MJB_SPEC_KERNEL == 1
 }  // namespace mjb
 // The one kernel of a specialised translation unit (generated by mjb_model_spec_source, loaded by mjb_spec_load): the fp32
 // step kernel with MJB_SPEC_ASSUME / MJB_SPEC_ASSUME_LAY pinning the sizes and LDS offsets of ONE compiled model.
@@ -120,13 +120,14 @@ namespace mjb {
 // (RK4 evaluates the dynamics at four states per step: no sharing.)  Jobs are laid out heaviest first, job-major, so that the
 // long ones start first.  Results are the ones the column-per-group kernel gave: a skipped stage would have recomputed the same numbers.
 template <typename T, typename TS, int G>
-__global__ __launch_bounds__(64) void k_fd(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, int ncol, T eps, T* y_out, int* valid, int cv, int cc) {
+MJB_DEV void k_fd_body(const DevModel<T>* mg, const Lay* lg, const DevData<TS>& d, int ncol, T eps, T* y_out, int* valid, int cv, int cc) {
   extern __shared__ __align__(16) char smem[];
   const int lane = threadIdx.x & (G - 1), sub = threadIdx.x / G;
   const long gid = (long)blockIdx.x * (64 / G) + sub;
   const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)mg;
   const Lay MJB_CONST* lp = (const Lay MJB_CONST*)lg;
-  ModelRef<T> m = *mp; LayRef L = *lp;
+  ModelRef<T> m = MJB_MODEL_OF(mp); LayRef L = *lp;
+  MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
   const int nq = m.nq, nv = m.nv, nu = m.nu;
   const int nCj = (1 + 2 * nu + cc - 1) / cc, nVj = (2 * nv + cv - 1) / cv, nQj = 2 * nv, njob = nCj + nVj + nQj;
   if (gid >= (long)d.batch * njob) return;
@@ -194,6 +195,20 @@ __global__ __launch_bounds__(64) void k_fd(const DevModel<T>* mg, const Lay* lg,
     gsync<G>();
   }
 }
+template <typename T, typename TS, int G>
+__global__ __launch_bounds__(64) void k_fd(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, int ncol, T eps, T* y_out, int* valid, int cv, int cc) {
+  k_fd_body<T, TS, G>(mg, lg, d, ncol, eps, y_out, valid, cv, cc);
+}
+#if defined(MJB_SPEC_KERNEL) && MJB_SPEC_KERNEL == 2
+}  // namespace mjb
+// The one kernel of a specialised FINITE-DIFFERENCE translation unit (mjb_fd_spec_source / mjb_fd_spec_load): k_fd<double, TS, G> with the
+// float64 layout's offsets and the model's sizes pinned and the model baked in as float64 constant data.
+extern "C" __global__ __launch_bounds__(64) void mjb_k_fd_spec(const mjb::DevModel<double>* mg, const mjb::Lay* lg, mjb::DevData<MJB_SPEC_TS> d, int ncol, double eps,
+                                                               double* y_out, int* valid, int cv, int cc) {
+  mjb::k_fd_body<double, MJB_SPEC_TS, MJB_SPEC_G>(mg, lg, d, ncol, eps, y_out, valid, cv, cc);
+}
+namespace mjb {
+#endif
 
 // A = d[dq';dv']/d[dq;dv]  (2nv x 2nv), B = d[dq';dv']/dctrl (2nv x nu), row-major per environment.
 template <typename T>

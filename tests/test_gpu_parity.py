@@ -603,3 +603,25 @@ def test_ticket_schedule_many_hand_overs(world, monkeypatch):
         res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc_warmstart", "time")]
     for a, b in zip(res["static"], res["tickets"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,B", [("humanoid", 24), ("cartpole", 512), ("drone2", 64)])
+def test_specialised_fd_kernel_is_bitwise_identical_to_the_generic_one(world, name, B):
+    """The per-model specialised float64 finite-difference kernel (sizes, float64 LDS layout and the model baked in; taken by the
+    first ``transition_fd``) gives bit for bit the (A, B) blocks of the generic ``k_fd``; its source for a data object equals the
+    one ``build()`` pre-compiles from the model alone, so a GPU box compiles nothing."""
+    import mujoco_template_amd._capi as capi
+
+    cm, om, dm = world(name)
+    res = {}
+    for spec in (False, None):
+        sim = BatchSim(dm, B, dtype="float32", specialize=spec)
+        sim.rollout(30, CTRL_RANDOM, seed=4, ctrl_scale=SCALE[name])
+        A, Bm = sim.transition_fd(1e-6, True)
+        assert sim.fd_specialized == (spec is None)
+        res[spec] = (A, Bm)
+        if spec is None:
+            assert sim.fd_spec_source() == dm.fd_spec_source()
+            assert os.path.exists(capi.compile_spec(dm.fd_spec_source()))
+    assert np.array_equal(res[False][0], res[None][0]) and np.array_equal(res[False][1], res[None][1])
+    assert np.isfinite(res[None][0]).all() and np.abs(res[None][0]).max() > 0
