@@ -290,10 +290,18 @@ struct EmitAlloc {
     return (const X*)(uintptr_t)(TOKEN + (unsigned long long)(n++) * 16ull + 16ull);
   }
   const float* putf(const std::vector<float>& v) {
-    return emit(v, "float", [](float x) { char b[48]; std::snprintf(b, sizeof(b), "%af", (double)x); return std::string(b); });
+    return emit(v, "float", [](float x) {
+      if (std::isnan(x)) return std::string("__builtin_nanf(\"\")");
+      if (std::isinf(x)) return std::string(x > 0 ? "__builtin_inff()" : "-__builtin_inff()");
+      char b[48]; std::snprintf(b, sizeof(b), "%af", (double)x); return std::string(b);             // hex float: exact
+    });
   }
   const double* putf(const std::vector<double>& v) {
-    return emit(v, "double", [](double x) { char b[48]; std::snprintf(b, sizeof(b), "%a", x); return std::string(b); });
+    return emit(v, "double", [](double x) {
+      if (std::isnan(x)) return std::string("__builtin_nan(\"\")");
+      if (std::isinf(x)) return std::string(x > 0 ? "__builtin_inf()" : "-__builtin_inf()");
+      char b[48]; std::snprintf(b, sizeof(b), "%a", x); return std::string(b);
+    });
   }
   const int* puti(const std::vector<int>& v) { return emit(v, "int", [](int x) { return std::to_string(x); }); }
   const unsigned long long* putu(const std::vector<unsigned long long>& v) {
