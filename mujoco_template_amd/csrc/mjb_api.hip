@@ -279,15 +279,30 @@ int auto_lanes(const HostModel& h, int lanes) { return lanes == 0 ? (h.nv <= 4 ?
 // DevModel<float> is then written out word by word as a struct of the same layout (pointer words -> the emitted arrays, everything
 // else -> the bit pattern), so the image cannot fall out of step with fill_dev_model or with the struct's member list.
 struct EmitAlloc {
-  std::string text;            // one `static const __constant__` array per table: its own symbol, so a lane-indexed read is
-  int n = 0;                   // global_load(table address + lane offset) with no further address arithmetic
+  // Two forms.  as_struct = false (default): one `static const __constant__` array per table - its own symbol, so a lane-indexed read
+  // is global_load(table address + lane offset) with no further address arithmetic.  as_struct = true (MJB_SPEC_BAKE=struct): every
+  // table a member of ONE struct - a single base address, an extra address add per lane-indexed read, far fewer address registers.
+  // Measured (scripts/gpu_spec_check.py, same box, B = 4096, M env-steps/s; pointer hops / struct / arrays): humanoid 41.7 / 43.1 /
+  // 43.4, drone2 178 / 193 / 218, cart-pole 215 / 230 / 248.  The humanoid kernel (256 VGPRs) spills 61 VGPRs to scratch with the
+  // array form (one spill store per env-step: HBM write traffic 0.15 -> 1.2 GB per 1000-step launch) and none with the struct form;
+  // it is still 0.8 % faster with the arrays.
+  bool as_struct = false;
+  std::string text, decl, init;
+  int n = 0;
   static constexpr unsigned long long TOKEN = 0x7E57AB1Eull << 32;
   template <typename X, typename F> const X* emit(const std::vector<X>& v, const char* ctype, F fmt) {
-    text += std::string("static const __constant__ ") + ctype + " mjb_tab_" + std::to_string(n) + "[] = {";
-    if (v.empty()) text += "0";
-    for (size_t i = 0; i < v.size(); i++) { if (i) text += (i % 16 == 0 ? ",\n " : ","); text += fmt(v[i]); }
-    text += "};\n";
+    std::string body;
+    if (v.empty()) body = "0";
+    for (size_t i = 0; i < v.size(); i++) { if (i) body += (i % 16 == 0 ? ",\n " : ","); body += fmt(v[i]); }
+    if (as_struct) {
+      decl += std::string("  ") + ctype + " t" + std::to_string(n) + "[" + std::to_string(v.empty() ? 1 : v.size()) + "];\n";
+      init += "  {" + body + "},\n";
+    } else text += std::string("static const __constant__ ") + ctype + " mjb_tab_" + std::to_string(n) + "[] = {" + body + "};\n";
     return (const X*)(uintptr_t)(TOKEN + (unsigned long long)(n++) * 16ull + 16ull);
+  }
+  std::string table_name(int k) const { return (as_struct ? "mjb_tabs.t" : "mjb_tab_") + std::to_string(k); }
+  std::string tables_source() const {
+    return as_struct ? "struct MjbBakedTables {\n" + decl + "};\nstatic const __constant__ MjbBakedTables mjb_tabs = {\n" + init + "};\n" : text;
   }
   const float* putf(const std::vector<float>& v) {
     return emit(v, "float", [](float x) {
@@ -310,10 +325,11 @@ struct EmitAlloc {
 };
 
 template <typename T>
-std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max) {
+std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max, bool as_struct) {
   static_assert(sizeof(DevModel<T>) % 8 == 0, "DevModel<T> is written out in 8-byte words");
   const char* tname = sizeof(T) == 4 ? "float" : "double";
   EmitAlloc ea;
+  ea.as_struct = as_struct;
   DevModel<T> m;
   fill_dev_model<T>(h, ea, ncon_max, nefc_max, m);
   const size_t nw = sizeof(m) / 8;
@@ -324,7 +340,7 @@ std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max) {
     const unsigned long long v = wv[i];
     if ((v >> 32) == (EmitAlloc::TOKEN >> 32)) {
       decl += " const void MJB_CONST* p" + std::to_string(i) + ";";
-      init += " (const void MJB_CONST*)mjb_tab_" + std::to_string((v - EmitAlloc::TOKEN) / 16 - 1) + ",";
+      init += " (const void MJB_CONST*)" + ea.table_name((int)((v - EmitAlloc::TOKEN) / 16 - 1)) + ",";
     } else {
       char b[64];
       decl += " unsigned a" + std::to_string(i) + ", b" + std::to_string(i) + ";";
@@ -335,7 +351,7 @@ std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max) {
   }
   decl += " };\n"; init += " };\n";
   std::string s = "#include \"mjb_types.hpp\"\n// the model as constant data of this translation unit (tables, then the DevModel image)\n";
-  s += ea.text + decl + init;
+  s += ea.tables_source() + decl + init;
   s += std::string("static_assert(sizeof(MjbBakedModel) == sizeof(mjb::DevModel<") + tname + ">), \"baked model image\");\n";
   s += std::string("#define MJB_SPEC_BAKED (*(const mjb::DevModel<") + tname + "> MJB_CONST*)&mjb_baked_model)\n";
   return s;
@@ -366,7 +382,12 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
   SL(i_con_pair); SL(i_scal); SL(nI); SL(bytes);
 #undef SL
   s += "\n";
-  if (!std::getenv("MJB_SPEC_NO_BAKE")) s += kind == 1 ? baked_model_source<float>(h, ncon_max, nefc_max) : baked_model_source<double>(h, ncon_max, nefc_max);
+  {
+    const char* e = std::getenv("MJB_SPEC_BAKE");                 // experiments: "off", "struct", "arrays"
+    const std::string mode = e ? e : "arrays";
+    if (mode != "off" && !std::getenv("MJB_SPEC_NO_BAKE"))
+      s += kind == 1 ? baked_model_source<float>(h, ncon_max, nefc_max, mode == "struct") : baked_model_source<double>(h, ncon_max, nefc_max, mode == "struct");
+  }
   s += "#include \"mjb_kernels.hpp\"\n";
   return s;
 }
