@@ -7,7 +7,7 @@ o=gpurun_out/$tag
 python3 scripts/summarize_profile.py r02_final $o/kt $o/pmc3 $o/pmc4 --envsteps-per-launch 4096000 --timed-launches 5 > /dev/null
 python3 scripts/summarize_profile.py r02_final_chunk100 $o/ckt $o/pmc1 $o/pmc2 $o/pmc5 --envsteps-per-launch 409600 --timed-launches 10 > /dev/null
 python3 scripts/summarize_profile.py r02_final_driver_shape $o/dkt $o/dpmc3 $o/dpmc4 --envsteps-per-launch 81920 --timed-launches 5 > /dev/null
-python3 scripts/summarize_profile.py r02_final_fd $o/fkt $o/fpmc1 $o/fpmc2 $o/fpmc3 $o/fpmc4 $o/fpmc5 --kernel "k_fd<double, float, 64>" --timed-launches 6 > /dev/null
+python3 scripts/summarize_profile.py r02_final_fd $o/fkt $o/fpmc1 $o/fpmc2 $o/fpmc3 $o/fpmc4 $o/fpmc5 --kernel "mjb_k_fd_spec" --timed-launches 6 > /dev/null
 cp $o/bench.json profiles/r02_final_bench.json
 cp $o/bench_driver_shape.json profiles/r02_final_bench_driver_shape.json
 python3 - <<'PY'
