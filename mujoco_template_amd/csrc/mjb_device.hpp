@@ -1731,7 +1731,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
   }
   gsync<G>();
   // reference acceleration: aref = -B (J qvel) - K imp (pos - margin)
-  const VecBcast<T, G> xv(qvel, nv, lane);
+  const VecLds<T> xv{qvel};
   for (int r = lane; r < nefc; r += G) {
     T v = dot_lds(J + r * nv, 1, xv, nv);
     earef[r] = -eB[r] * v - eK[r] * eI[r] * (epos[r] - emargin[r]);
@@ -1963,7 +1963,7 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *aref = w + L.efc_aref, *D = w + L.efc_D, *force = w + L.efc_force;
   T *qs = w + L.qfrc_smooth, *qas = w + L.qacc_smooth;
   T part = 0;
-  const VecBcast<T, G> xq(qacc, nv, lane);
+  const VecLds<T> xq{qacc};                                   // uniform-address LDS reads (merged into ds_read2_b64): fewer issue slots than one v_readlane per element
   // rows of M and rows of J in ONE pass over the stacked matrix [M; J] (nv + nefc rows usually fit the 64 lanes)
   for (int rho = lane; rho < nv + nefc; rho += G) {
     const bool ism = rho < nv;
@@ -2056,7 +2056,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     if (gn < gtol * gtol) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
-    const VecBcast<T, G> xs(search, nv, lane);
+    const VecLds<T> xs{search};
     for (int rho = lane; rho < nv + nefc; rho += G) {          // stacked [M; J] x search, one pass
       const bool ism = rho < nv;
       const int r = ism ? rho : rho - nv;
