@@ -125,6 +125,13 @@ long mjb_model_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int n
 long mjb_spec_source(mjbData* d, char* buf, long cap);
 int mjb_spec_load(mjbData* d, const void* code_object, long nbytes);
 int mjb_spec_unload(mjbData* d);
+/* The same for the TWO-WAVE step kernel that stepping launches use on small batches (one environment per 128-thread workgroup, the
+ * independent phases of a step side by side on its two wavefronts; fp32, one wave per environment, nv <= 32, Euler): results bitwise
+ * those of the one-wave kernel.  mjb_step_schedule()[5] tells whether a launch used it; MJB_TWO_WAVE=0 / 1 forces it off / on. */
+long mjb_model_step2_spec_source(mjbModel* m, int lanes, int nconmax, int nefcmax, char* buf, long cap);
+long mjb_step2_spec_source(mjbData* d, char* buf, long cap);
+int mjb_step2_spec_load(mjbData* d, const void* code_object, long nbytes);
+int mjb_step2_spec_unload(mjbData* d);
 /* The same for the float64 finite-difference kernel behind mjb_transition_fd (k_fd<double, TS, G> of this data object: float64 layout,
  * model baked in as float64 constants): source -> `hipcc --genco` -> mjb_fd_spec_load; results bitwise those of the generic kernel. */
 long mjb_model_fd_spec_source(mjbModel* m, int dtype, int lanes, int nconmax, int nefcmax, char* buf, long cap);   /* without a data object (build step) */
@@ -188,11 +195,11 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
  * and efc_type (int32 out).  Call mjb_debug_forward() first. */
 /* diagnostic build (-DMJB_PROFILE) only: per-phase shader-cycle sums since the last call, host_out[24]; zeros otherwise */
 int mjb_profile_get(mjbData* d, unsigned long long* host_out);
-/* How the last stepping launch (mjb_step / mjb_rollout / mjb_step_host) mapped work to workgroups: out5 = { steps of the launch,
+/* How the last stepping launch (mjb_step / mjb_rollout / mjb_step_host) mapped work to workgroups: out6 = { steps of the launch,
  * environment blocks, resident workgroup slots of the step kernel on this device (0 = unknown), chunk_steps (0 = static map: one
- * workgroup per block for all steps; > 0 = the resident workgroups drew (block, chunk) tickets), fair_bit (0 = hardware age order) }.
+ * workgroup per block for all steps; > 0 = the resident workgroups drew (block, chunk) tickets), fair_bit (0 = hardware age order), 1 if the launch used two wavefronts per environment (small batches) }.
  * The engine picks the map itself (more blocks than slots -> tickets); MJB_CHUNK_STEPS / MJB_FAIR_BIT override it for experiments. */
-int mjb_step_schedule(mjbData* d, int* out5);
+int mjb_step_schedule(mjbData* d, int* out6);
 /* diagnostic kernel (-DMJB_TIMELINE) only: per environment [start, end] of its wave in the last launch (100 MHz clock), HW_ID, XCC_ID */
 int mjb_profile_env_get(mjbData* d, unsigned long long* host_out /* [batch, 4] */);
 int mjb_debug_forward(mjbData* d);

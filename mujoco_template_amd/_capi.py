@@ -74,6 +74,12 @@ def load_library() -> ctypes.CDLL:
     L.mjb_spec_source.restype = cl
     L.mjb_spec_load.argtypes = [vp, ctypes.c_char_p, cl]
     L.mjb_spec_unload.argtypes = [vp]
+    L.mjb_model_step2_spec_source.argtypes = [vp, ci, ci, ci, ctypes.c_char_p, cl]
+    L.mjb_model_step2_spec_source.restype = cl
+    L.mjb_step2_spec_source.argtypes = [vp, ctypes.c_char_p, cl]
+    L.mjb_step2_spec_source.restype = cl
+    L.mjb_step2_spec_load.argtypes = [vp, ctypes.c_char_p, cl]
+    L.mjb_step2_spec_unload.argtypes = [vp]
     L.mjb_model_fd_spec_source.argtypes = [vp, ci, ci, ci, ci, ctypes.c_char_p, cl]
     L.mjb_model_fd_spec_source.restype = cl
     L.mjb_fd_spec_source.argtypes = [vp, ctypes.c_char_p, cl]
@@ -124,7 +130,7 @@ def load_library() -> ctypes.CDLL:
     L.mjb_step_host.argtypes = [vp, ci, ci]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
-                 "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_fd_spec_load", "mjb_fd_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
+                 "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_fd_spec_load", "mjb_fd_spec_unload", "mjb_step2_spec_load", "mjb_step2_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get", "mjb_model_field", "mjb_model_field_at", "mjb_model_save",
                  "mjb_model_load", "mjb_model_load_xml", "mjb_model_load_xml_string", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
                  "mjb_step_host"):
@@ -413,6 +419,13 @@ class DeviceModel:
         """Translation unit of the specialised fp32 step kernel for these creation arguments (no GPU needed)."""
         return _source_from(load_library().mjb_model_spec_source, self.ptr, MJB_F32, int(lanes), int(nconmax), int(nefcmax))
 
+    def step2_spec_source(self, *, lanes: int = 0, nconmax: int = 0, nefcmax: int = 0) -> str | None:
+        """Translation unit of the specialised two-wave step kernel (small batches), or None when that kernel does not apply to the model."""
+        try:
+            return _source_from(load_library().mjb_model_step2_spec_source, self.ptr, int(lanes), int(nconmax), int(nefcmax))
+        except TemplateError:
+            return None
+
     def fd_spec_source(self, *, dtype: str = "float32", lanes: int = 0, nconmax: int = 0, nefcmax: int = 0) -> str:
         """Translation unit of the specialised float64 finite-difference kernel for these creation arguments (no GPU needed)."""
         return _source_from(load_library().mjb_model_fd_spec_source, self.ptr, MJB_F32 if dtype == "float32" else MJB_F64, int(lanes), int(nconmax), int(nefcmax))
@@ -477,8 +490,18 @@ class BatchSim:
         image = _read_private(compile_spec(self.spec_source()))
         _check(load_library().mjb_spec_load(self.ptr, image, len(image)))
         self.specialized = True
+        # small batches are stepped by the two-wave kernel where it applies: specialise that one too
+        if self.batch <= 512:
+            try:
+                src2 = _source_from(load_library().mjb_step2_spec_source, self.ptr)
+            except TemplateError:
+                src2 = None
+            if src2 is not None:
+                image2 = _read_private(compile_spec(src2))
+                _check(load_library().mjb_step2_spec_load(self.ptr, image2, len(image2)))
 
     def unspecialize(self) -> None:
+        _check(load_library().mjb_step2_spec_unload(self.ptr))
         _check(load_library().mjb_spec_unload(self.ptr))
         self.specialized = False
 
@@ -654,10 +677,10 @@ class BatchSim:
 
     def schedule_info(self) -> dict:
         """How the last stepping launch mapped work to workgroups (``mjb_step_schedule``)."""
-        out = np.zeros(5, dtype=np.int32)
+        out = np.zeros(6, dtype=np.int32)
         _check(load_library().mjb_step_schedule(self.ptr, out.ctypes.data))
         return {"launch_steps": int(out[0]), "env_blocks": int(out[1]), "resident_slots": int(out[2]), "chunk_steps": int(out[3]),
-                "map": "tickets" if out[3] > 0 else "static", "fair_bit": int(out[4])}
+                "map": "tickets" if out[3] > 0 else "static", "fair_bit": int(out[4]), "waves_per_env": 2 if out[5] else 1}
 
     def profile_env_get(self) -> np.ndarray:
         out = np.zeros((self.batch, 4), dtype=np.uint64)

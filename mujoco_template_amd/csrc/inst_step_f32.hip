@@ -8,6 +8,10 @@ hipError_t launch_step<float, float>(int G, const DevModel<float>* m, const Lay*
   return hipErrorInvalidValue;
 }
 template <>
+hipError_t launch_step2<float, float>(const DevModel<float>* m, const Lay* Ldev, const Lay& L, const DevData<float>& d, const StepArgs& a, const ObsSpecDev& obs, float* obs_out, hipStream_t stream) {
+  return launch_step2_impl<float, float>(m, Ldev, L, d, a, obs, obs_out, stream);
+}
+template <>
 int step_blocks_per_cu<float, float>(int G, const Lay& L) {
   switch (G) {
     case 8: return step_blocks_per_cu_g<float, float, 8>(L);

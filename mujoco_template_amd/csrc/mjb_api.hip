@@ -76,6 +76,11 @@ struct mjbData {
   DevModel<float>* mf_dev = nullptr;    // device copies of the structs above (read through the constant address space)
   DevModel<double>* md_dev = nullptr;
   Lay *Lf_dev = nullptr, *Ld_dev = nullptr;
+  Lay Lf2;                                  // flat fp32 layout of the two-wave step kernel (k_step2); bytes == 0: that kernel does not apply
+  Lay* Lf2_dev = nullptr;
+  hipModule_t spec2_mod = nullptr;          // per-model specialised two-wave kernel (mjb_step2_spec_load)
+  hipFunction_t spec2_fn = nullptr;
+  int two_wave = -1;                        // MJB_TWO_WAVE: 0 never, 1 whenever it applies, -1 (default) the policy in launch()
   int up_disable = -1, up_iter = -1; double up_tol = -1;
   DevData<float> df;
   DevData<double> dd;
@@ -99,7 +104,7 @@ struct mjbData {
   int sched_chunk = -1, fair_bit = -1;     // experiment overrides (MJB_CHUNK_STEPS, MJB_FAIR_BIT); -1 = policy below
   unsigned launch_seq = 0;                 // ticket launches so far (tags of the hand-over buffer)
   unsigned long long ticket_next = 0;      // value of the device ticket counter when the next ticket launch starts
-  int last_sched[5] = {0, 0, 0, 0, 0};     // of the last mode-0 launch: steps, environment blocks, resident slots, chunk_steps, fair_bit
+  int last_sched[6] = {0, 0, 0, 0, 0, 0};  // of the last mode-0 launch: steps, environment blocks, resident slots, chunk_steps, fair_bit, two waves per environment
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   double *fd_A_host = nullptr, *fd_B_host = nullptr;          // pinned: the (A, B) blocks leave the device in one async copy each
@@ -362,7 +367,8 @@ std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max, b
 // kind 1: the fp32 step kernel (L = the fp32 layout); kind 2: the float64 finite-difference kernel k_fd<double, ts, G> (L = the float64 layout)
 std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, int nefc_max, int kind = 1, const char* ts = "float") {
   std::string s = kind == 1 ? "// generated by mjb_model_spec_source(): size- and layout-specialised k_step<float, float, G> of ONE compiled model\n"
-                            : "// generated by mjb_fd_spec_source(): size- and layout-specialised k_fd<double, TS, G> of ONE compiled model\n";
+                : kind == 2 ? "// generated by mjb_fd_spec_source(): size- and layout-specialised k_fd<double, TS, G> of ONE compiled model\n"
+                            : "// generated by mjb_step2_spec_source(): size- and (flat) layout-specialised two-wave step kernel k_step2<float, float> of ONE compiled model\n";
   s += "#define MJB_SPEC_KERNEL " + std::to_string(kind) + "\n#define MJB_SPEC_TS " + ts + "\n#define MJB_SPEC_G " + std::to_string(G) + "\n#define MJB_SPEC_ASSUME(m)";
   auto A = [&](const char* obj, const char* f, long v) { s += std::string(" __builtin_assume((") + obj + ")." + f + " == " + std::to_string(v) + ");"; };
 #define SM(f, v) A("m", #f, (long)(v))
@@ -379,14 +385,14 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
   SL(site_xmat); SL(subtree_com); SL(cinert); SL(crb); SL(cdof); SL(cdof_dot); SL(cvel); SL(cacc); SL(cfrc); SL(dofbuf); SL(bfrc); SL(M); SL(W);
   SL(ten_length); SL(ten_J); SL(act_force); SL(sens); SL(con); SL(efc_J); SL(efc_pos); SL(efc_D); SL(efc_aref); SL(efc_jar); SL(efc_jv);
   SL(efc_force); SL(efc_KBI); SL(Ma); SL(grad); SL(search); SL(Mv); SL(tmp); SL(cholcol); SL(rk); SL(nT); SL(i_efc_type); SL(i_efc_id);
-  SL(i_con_pair); SL(i_scal); SL(nI); SL(bytes);
+  SL(i_con_pair); SL(i_scal); SL(i_mail); SL(nI); SL(bytes);
 #undef SL
   s += "\n";
   {
     const char* e = std::getenv("MJB_SPEC_BAKE");                 // experiments: "off", "struct", "arrays"
     const std::string mode = e ? e : "arrays";
     if (mode != "off" && !std::getenv("MJB_SPEC_NO_BAKE"))
-      s += kind == 1 ? baked_model_source<float>(h, ncon_max, nefc_max, mode == "struct") : baked_model_source<double>(h, ncon_max, nefc_max, mode == "struct");
+      s += kind != 2 ? baked_model_source<float>(h, ncon_max, nefc_max, mode == "struct") : baked_model_source<double>(h, ncon_max, nefc_max, mode == "struct");
   }
   s += "#include \"mjb_kernels.hpp\"\n";
   return s;
@@ -457,6 +463,31 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
     a.ticket_base = (unsigned)d->ticket_next;
     d->ticket_next += adv;
   }
+  // Two waves per environment (env_run2) when the batch leaves at least half of the step kernel's resident slots empty: stepping
+  // launches only (mode 0, no debug dumps), fp32, one wave per environment, nv <= 32, Euler.
+  bool two = false;
+  if (a.mode == 0 && !debug && d->dtype == MJB_F32 && d->Lf2.bytes > 0 && a.chunk_steps == 0) {
+    if (d->two_wave == -1) { const char* e2 = std::getenv("MJB_TWO_WAVE"); d->two_wave = e2 ? (std::atoi(e2) ? 1 : 0) : 2; }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || ncu < 1) ncu = 256;
+    // every environment must be resident at once and have two SIMDs to itself: the kernel is built for one wave per SIMD
+    // (__launch_bounds__(128, 1)), i.e. two workgroups per CU; measured on the humanoid: x1.14 .. 1.17 up to 512 environments,
+    // x0.6 beyond (profiles/r02_two_wave.log)
+    long wg_per_cu = d->Lf2.bytes > 0 ? (160L * 1024) / d->Lf2.bytes : 0;
+    if (wg_per_cu > 2) wg_per_cu = 2;
+    two = d->two_wave == 1 || (d->two_wave == 2 && (long)d->batch <= wg_per_cu * ncu);
+  }
+  d->last_sched[5] = two ? 1 : 0;
+  if (two) {
+    a.fair_bit = 0;
+    if (d->spec2_fn) {
+      DevDebug<float> dbgarg; std::memset(&dbgarg, 0, sizeof(dbgarg));
+      const DevModel<float>* mg = d->mf_dev; const Lay* lg = d->Lf2_dev;
+      DevData<float> dv = d->df; StepArgs av = a; ObsSpecDev ov = obs; float* oo = (float*)obs_out;
+      void* args[] = {(void*)&mg, (void*)&lg, (void*)&dv, (void*)&dbgarg, (void*)&av, (void*)&ov, (void*)&oo};
+      e = hipModuleLaunchKernel(d->spec2_fn, (unsigned)d->batch, 1, 1, 128, 1, 1, (unsigned)d->Lf2.bytes, d->stream, args, nullptr);
+    } else e = launch_step2<float, float>(d->mf_dev, d->Lf2_dev, d->Lf2, d->df, a, obs, (float*)obs_out, d->stream);
+  } else
   if (d->dtype == MJB_F32 && d->spec_fn) {               // per-model specialised kernel: same arguments, same grid
     DevDebug<float> dbgarg; std::memset(&dbgarg, 0, sizeof(dbgarg));
     if (debug) dbgarg = d->dbgf;
@@ -561,7 +592,13 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
     mjb_data_free(d);
     return fail(MJB_ERR_ARG, buf);
   }
-  if (dev_alloc(d, &d->mf_dev, 1) || dev_alloc(d, &d->md_dev, 1) || dev_alloc(d, &d->Lf_dev, 1) || dev_alloc(d, &d->Ld_dev, 1) ||
+  std::memset(&d->Lf2, 0, sizeof(Lay));
+  if (dtype == MJB_F32 && d->G == 64 && h.nv <= 32 && h.integrator != INT_RK4) {
+    d->Lf2 = make_layout(h, d->ncon_max, d->nefc_max, sizeof(float), true);
+    if ((size_t)d->Lf2.bytes > 64 * 1024) std::memset(&d->Lf2, 0, sizeof(Lay));       // (never for the models this path is for)
+  }
+  if (dev_alloc(d, &d->mf_dev, 1) || dev_alloc(d, &d->md_dev, 1) || dev_alloc(d, &d->Lf_dev, 1) || dev_alloc(d, &d->Ld_dev, 1) || dev_alloc(d, &d->Lf2_dev, 1) ||
+      hipMemcpy(d->Lf2_dev, &d->Lf2, sizeof(Lay), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d->Lf_dev, &d->Lf, sizeof(Lay), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d->Ld_dev, &d->Ld, sizeof(Lay), hipMemcpyHostToDevice) != hipSuccess) {
     mjb_data_free(d);
@@ -579,6 +616,7 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
 void mjb_data_free(mjbData* d) {
   if (d && d->spec_mod) { hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; }
   if (d && d->fd_spec_mod) { hipModuleUnload(d->fd_spec_mod); d->fd_spec_mod = nullptr; d->fd_spec_fn = nullptr; }
+  if (d && d->spec2_mod) { hipModuleUnload(d->spec2_mod); d->spec2_mod = nullptr; d->spec2_fn = nullptr; }
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : d->owned) (void)hipFree(p);
@@ -735,6 +773,45 @@ int mjb_spec_load(mjbData* d, const void* image, long nbytes) {
 int mjb_spec_unload(mjbData* d) {
   if (!d) return fail(MJB_ERR_ARG, "data is NULL");
   if (d->spec_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->spec_mod); d->spec_mod = nullptr; d->spec_fn = nullptr; d->step_slots = -1; }
+  return MJB_OK;
+}
+
+// the two-wave step kernel (small batches) of this data object / of a model's default creation arguments
+long mjb_step2_spec_source(mjbData* d, char* buf, long cap) {
+  if (!d) { fail(MJB_ERR_ARG, "data is NULL"); return -1; }
+  if (d->Lf2.bytes <= 0) { fail(MJB_ERR_ARG, "the two-wave step kernel does not apply to this data object (fp32, one wave per environment, nv <= 32, Euler)"); return -1; }
+  const std::string src = spec_source(d->model->h, d->Lf2, 64, d->ncon_max, d->nefc_max, 3, "float");
+  if (buf && cap > (long)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+  return (long)src.size();
+}
+long mjb_model_step2_spec_source(mjbModel* m, int lanes, int nconmax, int nefcmax, char* buf, long cap) {
+  if (!m) { fail(MJB_ERR_ARG, "model is NULL"); return -1; }
+  const HostModel& h = m->h;
+  lanes = auto_lanes(h, lanes);
+  if (lanes != 64 || h.nv > 32 || h.integrator == INT_RK4) { fail(MJB_ERR_ARG, "the two-wave step kernel does not apply to this model"); return -1; }
+  int nc, ne;
+  choose_caps(h, MJB_F32, lanes, nconmax, nefcmax, nc, ne);
+  const std::string src = spec_source(h, make_layout(h, nc, ne, sizeof(float), true), 64, nc, ne, 3, "float");
+  if (buf && cap > (long)src.size()) std::memcpy(buf, src.c_str(), src.size() + 1);
+  return (long)src.size();
+}
+int mjb_step2_spec_load(mjbData* d, const void* image, long nbytes) {
+  if (!d || !image || nbytes <= 0) return fail(MJB_ERR_ARG, "NULL argument");
+  if (d->Lf2.bytes <= 0) return fail(MJB_ERR_ARG, "the two-wave step kernel does not apply to this data object");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  if (d->spec2_mod) { hipModuleUnload(d->spec2_mod); d->spec2_mod = nullptr; d->spec2_fn = nullptr; }
+  hipModule_t mod; hipFunction_t fn;
+  hipError_t e = hipModuleLoadData(&mod, image);
+  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+  e = hipModuleGetFunction(&fn, mod, "mjb_k_step2_spec");
+  if (e != hipSuccess) { hipModuleUnload(mod); return fail(MJB_ERR_DEVICE, "code object has no mjb_k_step2_spec kernel"); }
+  d->spec2_mod = mod; d->spec2_fn = fn;
+  return MJB_OK;
+}
+int mjb_step2_spec_unload(mjbData* d) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  if (d->spec2_mod) { HIPCHK(hipStreamSynchronize(d->stream)); hipModuleUnload(d->spec2_mod); d->spec2_mod = nullptr; d->spec2_fn = nullptr; }
   return MJB_OK;
 }
 
@@ -1288,9 +1365,9 @@ int mjb_profile_get(mjbData* d, unsigned long long* host_out /* [24] per-phase c
   return MJB_OK;
 }
 
-int mjb_step_schedule(mjbData* d, int* out5) {
-  if (!d || !out5) return fail(MJB_ERR_ARG, "NULL argument");
-  for (int i = 0; i < 5; i++) out5[i] = d->last_sched[i];
+int mjb_step_schedule(mjbData* d, int* out6) {
+  if (!d || !out6) return fail(MJB_ERR_ARG, "NULL argument");
+  for (int i = 0; i < 6; i++) out6[i] = d->last_sched[i];
   return MJB_OK;
 }
 

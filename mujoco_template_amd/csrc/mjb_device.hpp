@@ -794,8 +794,10 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
 // two pivot diagonal entries need a "-2" fix-up.  After all pivots acc = -A^-1 and the solve is a 16-FMA mat-vec per lane:
 // no factor in LDS, no forward/backward substitution chains.  The matrix stays symmetric, so "column j as a lane vector"
 // is one register (+ a half swap) at every step.
+// Two halves, so that the two-wave step kernel (k_step2) can invert M + h D while the other wave still solves the constraints:
+// mfma_sweep_invert32 leaves -A^-1 in the accumulator, mfma_sweep_apply32 is the mat-vec.  mfma_sweep_solve32 = both.
 template <typename MRef>
-MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, const float* dw, int nefc, int mode, int n, int lane, unsigned long long* pf = nullptr) {
   const int h = lane >> 5, c_ = lane & 31;
   unsigned long long tq0 = pf ? MJB_MEMTIME() : 0;
   mjb_f16v acc;
@@ -813,7 +815,6 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
       float v = k < nlim ? mv : 0.0f;
       acc[i] = k == rdiff ? v + dadd : v;
     }
-    if (h == 0) bpad[c] = c < n ? x[c] : 0.0f;                 // right-hand side, zero-padded to 32
     if (mode == 1) {
       // Hessian M + J^T D J: one rank-2 MFMA per PAIR OF ACTIVE ROWS (D != 0), the next pair's J loads in flight
       // while the current MFMA runs.
@@ -859,7 +860,14 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
     acc[ij + 1] -= ln == 32 * hj + j1 ? 2.0f : 0.0f;
     acc = MJB_MFMA(aop, bop, acc);
   }
+  if (pf) { unsigned long long tq2 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; }
+  return acc;
+}
+// x <- A^-1 x with acc = -A^-1 from mfma_sweep_invert32 (bpad: 32 words of LDS for the zero-padded right-hand side)
+MJB_DEV void mfma_sweep_apply32(const mjb_f16v& acc, float* bpad, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c_ = lane & 31;
   unsigned long long tq2 = pf ? MJB_MEMTIME() : 0;
+  if (h == 0) bpad[c_] = c_ < n ? x[c_] : 0.0f;               // right-hand side, zero-padded to 32
   gsync<64>();
   {
     const float* bp = bpad + 4 * h;
@@ -871,7 +879,12 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
     if (h == 0 && c_ < n) x[c_] = -tot;                       // acc = -A^-1
     gsync<64>();
   }
-  if (pf) { unsigned long long tq3 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
+  if (pf) pf[2] += MJB_MEMTIME() - tq2;
+}
+template <typename MRef>
+MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const mjb_f16v acc = mfma_sweep_invert32<MRef>(m, M, J, dw, nefc, mode, n, lane, pf);
+  mfma_sweep_apply32(acc, bpad, n, lane, x, pf);
 }
 template <typename MRef>
 MJB_DEV void mfma_sweep_solve32(MRef, const double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
@@ -1536,7 +1549,7 @@ template <typename T, int G> MJB_DEV void collision(Ctx<T>& c) {
     gsync<G>();
     if (nl > 0) collide_pass<T, G>(c, lane < nl ? cand[lane] : 0, lane < nl, ncon, dropped);
   }
-  c.con_dropped = dropped;
+  c.con_dropped += dropped;                                   // over all steps of this call (the launch's counters add it up)
   c.ncon = ncon < m.ncon_max ? ncon : m.ncon_max;
   gsync<G>();
 }
@@ -1688,7 +1701,7 @@ template <typename T, int G> MJB_DEV void make_constraint(Ctx<T>& c) {
     }
     nefc = gmaxi<G>(last);
   }
-  c.nefc = nefc; c.efc_dropped = dropped;
+  c.nefc = nefc; c.efc_dropped += dropped;
   gsync<G>();
   // Jacobian rows of limits
   {
@@ -2224,7 +2237,8 @@ template <typename T, int G> MJB_DEV void integrate_pos(ModelRef<T> m, T* qpos, 
 }
 
 // A11 Euler with implicit joint damping (mj_Euler)
-template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
+// inv != nullptr (two-wave step kernel, fp32, nv <= 32): -(M + h D)^-1 already sits in that accumulator
+template <typename T, int G> MJB_DEV void euler(Ctx<T>& c, const mjb_f16v* inv = nullptr) {
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv;
   T *qacc = w + L.qacc, *qvel = w + L.qvel, *qpos = w + L.qpos, *tmpv = w + L.Mv, *M = w + L.M, *W = w + L.W;
   T h = m.timestep;
@@ -2232,6 +2246,12 @@ template <typename T, int G> MJB_DEV void euler(Ctx<T>& c) {
     T *qs = w + L.qfrc_smooth, *qc = w + L.qfrc_constraint;
     for (int i = lane; i < nv; i += G) tmpv[i] = qs[i] + qc[i];
     gsync<G>();
+#ifndef MJB_HOST_EMU
+    if constexpr (sizeof(T) == 4 && G == 64) {
+      if (inv) mfma_sweep_apply32(*inv, w + L.tmp, nv, lane, tmpv);
+      else factor_W<T, G>(c, 2, tmpv);
+    } else
+#endif
     factor_W<T, G>(c, 2, tmpv);
   } else {
     for (int i = lane; i < nv; i += G) tmpv[i] = qacc[i];
@@ -2618,5 +2638,126 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
     for (int i = lane; i < 6 * m.nbody; i += G) dbg.cvel[(size_t)env * 6 * m.nbody + i] = (TS)w[L.cvel + i];
   }
 }
+
+
+// ---------------------------------------------------------------------------
+// Two waves per environment (k_step2, mjb_kernels.hpp): for batches that leave most of the chip idle (no more environments than
+// half the resident slots of k_step) one environment is stepped by a 128-thread workgroup whose two wavefronts run the phases of a
+// step that do not depend on each other side by side, on a FLAT LDS layout (make_layout(..., flat): temporaries of different
+// overlay groups are live at the same time):
+//     wave 0: [bad-state checks, ctrl, kinematics] | com_pos, crb       | bias / passive forces | actuation, M^-1, Newton solver, sensors |        | obs, I/O
+//     wave 1:                 (waits)              | collision          | constraint rows       | -(M + h D)^-1 in registers             | Euler  |
+// separated by s_barrier.  The phases are the very functions of the one-wave kernel in an order that respects their data
+// dependences, so the results are bitwise those of k_step (tests: test_two_wave_kernel_is_bitwise_identical).  fp32, nv <= 32,
+// Euler integrator, stepping mode only; everything else stays on k_step.
+// ---------------------------------------------------------------------------
+#ifndef MJB_HOST_EMU
+template <typename T, typename TS>
+MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, DataRef<TS> d, ArgsRef a, ObsRef obs, TS* obs_out, T* w, int* wi, int env, int lane, int wv) {
+  constexpr int G = 64;
+  Ctx<T> c(mp, lp, w, wi, lane);
+  ModelRef<T> m = MJB_MODEL_OF(mp); LayRef L = *lp;
+  MJB_SPEC_ASSUME(m) MJB_SPEC_ASSUME_LAY(L)
+  const int nq = m.nq, nv = m.nv, nu = m.nu;
+  int* mail = wi + L.i_mail;                 // [0] ncon [1] nefc [2] contacts dropped (total) [3] rows dropped (total) [4] bad acceleration in this pass
+  double time = 0;
+  int badqpos = 0, badqvel = 0, badqacc = 0;
+  if (wv == 0) {
+    for (int i = lane; i < nq; i += G) w[L.qpos + i] = (T)d.qpos[(size_t)env * nq + i];
+    for (int i = lane; i < nv; i += G) {
+      w[L.qvel + i] = (T)d.qvel[(size_t)env * nv + i];
+      w[L.qacc_ws + i] = (T)d.qacc_warmstart[(size_t)env * nv + i];
+      w[L.qacc + i] = (T)d.qacc[(size_t)env * nv + i];
+    }
+    for (int i = lane; i < nu; i += G) w[L.ctrl + i] = a.ctrl_mode == CTRL_ZERO ? (T)0 : (T)d.ctrl[(size_t)env * nu + i];
+    for (int i = lane; i < nv * nv; i += G) w[L.M + i] = 0;     // structural zeros of the mass matrix
+    if (lane < 8) mail[lane] = 0;
+    time = d.time[env];
+  }
+  __syncthreads();
+  for (int s = 0; s < a.nstep; s++) {
+    if (wv == 0) {
+      if (group_bad<T, G>(w + L.qpos, nq, lane)) { badqpos++; reset_state<T, G>(c); time = 0; }
+      if (group_bad<T, G>(w + L.qvel, nv, lane)) { badqvel++; reset_state<T, G>(c); time = 0; }
+      if (a.ctrl_mode == CTRL_RANDOM) {
+        random_ctrl<T, G>(m, w + L.ctrl, a.seed, a.env0 + (unsigned)env, a.step0 + (unsigned)s, (T)a.ctrl_scale, lane);
+        gsync<G>();
+      } else if (a.ctrl_mode == CTRL_FEEDBACK) feedback_ctrl<T, G>(c, a, a.env0 + (unsigned)env, a.step0 + (unsigned)s);
+    }
+    mjb_f16v inv;
+    for (int pass = 0; pass < 2; pass++) {                      // pass 1 only after a bad-acceleration reset (like k_step's retry)
+      if (wv == 0) kinematics<T, G>(c);
+      __syncthreads();
+      if (wv == 0) { com_pos<T, G>(c); crb_factor<T, G>(c); }
+      else {
+        collision<T, G>(c);
+        if (lane == 0) { mail[0] = c.ncon; mail[2] = c.con_dropped; }
+      }
+      __syncthreads();
+      if (wv == 0) vel_bias_passive<T, G>(c);
+      else {
+        make_constraint<T, G>(c);
+        if (lane == 0) { mail[1] = c.nefc; mail[3] = c.efc_dropped; }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        c.ncon = mail[0]; c.nefc = mail[1];
+        actuation_acceleration<T, G>(c);
+        solve_constraints<T, G>(c);
+        if (m.nsensor > 0) { sensors<T, T, G>(c, w + L.sens); gsync<G>(); }
+        const bool bad = pass == 0 && group_bad<T, G>(w + L.qacc, nv, lane);
+        if (lane == 0) mail[4] = bad ? 1 : 0;
+      } else if (m.has_damping) {
+        inv = mfma_sweep_invert32<ModelRef<T>>(m, w + L.M, w + L.efc_J, w + L.efc_jv, 0, 2, nv, lane);
+      }
+      __syncthreads();
+      if (mail[4] == 0) break;
+      if (wv == 0) { badqacc++; reset_state<T, G>(c); time = 0; }
+      __syncthreads();
+    }
+    if (wv == 1) euler<T, G>(c, m.has_damping ? &inv : nullptr);
+    __syncthreads();
+    if (wv == 0) {
+      time += a.dt;
+      if (a.obs_every > 0 && ((s + 1) % a.obs_every) == 0) {
+        size_t slot = (size_t)((s + 1) / a.obs_every - 1);
+        write_obs<T, TS, G>(c, obs, time, obs_out + (slot * (size_t)d.batch + (size_t)env) * (size_t)obs.dim);
+      }
+    }
+  }
+  if (wv != 0) return;
+  if (lane == 0) {
+    int* cn = d.counters + (size_t)env * CNT_N;
+    const int cdrop = mail[2], edrop = mail[3];
+    if (cdrop) atomicAdd(cn + CNT_CON_DROPPED, cdrop);
+    if (edrop) atomicAdd(cn + CNT_EFC_DROPPED, edrop);
+    if (badqpos) atomicAdd(cn + CNT_BADQPOS, badqpos);
+    if (badqvel) atomicAdd(cn + CNT_BADQVEL, badqvel);
+    if (badqacc) atomicAdd(cn + CNT_BADQACC, badqacc);
+    const int fl = (cdrop ? 1 : 0) | (edrop ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0);
+    if (fl && d.flags) atomicOr(d.flags, fl);
+    d.time[env] = time;
+    cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
+  }
+  for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
+  for (int i = lane; i < nv; i += G) {
+    d.qvel[(size_t)env * nv + i] = (TS)w[L.qvel + i];
+    d.qacc[(size_t)env * nv + i] = (TS)w[L.qacc + i];
+    d.qacc_warmstart[(size_t)env * nv + i] = (TS)w[L.qacc_ws + i];
+  }
+  if (a.ctrl_mode != CTRL_KEEP) for (int i = lane; i < nu; i += G) d.ctrl[(size_t)env * nu + i] = (TS)w[L.ctrl + i];
+  if (a.write_kin) {
+    for (int i = lane; i < 3 * m.nbody; i += G) {
+      d.xpos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xpos + i];
+      d.xipos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xipos + i];
+      d.subtree_com[(size_t)env * 3 * m.nbody + i] = (TS)w[L.subtree_com + i];
+    }
+    for (int i = lane; i < 4 * m.nbody; i += G) d.xquat[(size_t)env * 4 * m.nbody + i] = (TS)w[L.xquat + i];
+    for (int i = lane; i < 3 * m.nsite; i += G) d.site_xpos[(size_t)env * 3 * m.nsite + i] = (TS)w[L.site_xpos + i];
+    for (int i = lane; i < 3 * m.ngeom; i += G) d.geom_xpos[(size_t)env * 3 * m.ngeom + i] = (TS)w[L.geom_xpos + i];
+    for (int i = lane; i < m.nsensordata; i += G) d.sensordata[(size_t)env * m.nsensordata + i] = (TS)w[L.sens + i];
+  }
+}
+#endif
 
 }  // namespace mjb

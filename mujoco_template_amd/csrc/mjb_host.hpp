@@ -367,7 +367,8 @@ void fill_dev_model(const HostModel& h, Alloc& alloc, int ncon_max, int nefc_max
   m.key_qpos = F("key_qpos"); m.key_qvel = F("key_qvel"); m.key_ctrl = F("key_ctrl"); m.key_time = F("key_time");
 }
 
-inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t sizeofT) {
+// flat = true: no overlay of temporaries (the two-wave step kernel runs phases of different overlay groups at the same time)
+inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t sizeofT, bool flat = false) {
   Lay L;
   std::memset(&L, 0, sizeof(L));
   int o = 0;
@@ -392,11 +393,11 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   //   g5 (solver .. integrator):     Ma, grad, search, Mv, cholcol, jar, jv, force
   int r0 = o, rend = o;
   L.xmat = A(9 * nb); L.xanchor = A(3 * nj); L.xaxis = A(3 * nj); L.geom_xmat = A(9 * ng);
-  if (o > rend) rend = o; o = r0;
+  if (o > rend) rend = o; if (!flat) o = r0;
   L.crb = A(10 * nb); L.dofbuf = A(6 * nv);
-  if (o > rend) rend = o; o = r0;
+  if (o > rend) rend = o; if (!flat) o = r0;
   L.cdof_dot = A(6 * nv); if (!h.has_accel) L.cacc = A(6 * nb); L.cfrc = A(6 * nb);
-  if (o > rend) rend = o; o = r0;
+  if (o > rend) rend = o; if (!flat) o = r0;
   L.Ma = A(nv); L.grad = A(nv); L.search = A(nv); L.Mv = A(nv); L.cholcol = A(nv + 1);
   L.efc_jar = A(nefc_max); L.efc_jv = A(nefc_max); L.efc_force = A(nefc_max); L.efc_KBI = A(nefc_max);
   if (o > rend) rend = o;
@@ -406,6 +407,7 @@ inline Lay make_layout(const HostModel& h, int ncon_max, int nefc_max, size_t si
   int oi = 0;
   auto AI = [&](int n) { int r = oi; oi += n > 0 ? n : 0; return r; };
   L.i_efc_type = AI(nefc_max); L.i_efc_id = L.i_efc_type; L.i_con_pair = AI(ncon_max); L.i_scal = L.i_con_pair;   // ids are packed into the same words
+  L.i_mail = AI(8);
   L.nI = oi;
   size_t bytes = (size_t)L.nT * sizeofT + (size_t)L.nI * sizeof(int);
   L.bytes = (int)((bytes + 15) / 16 * 16);

@@ -97,6 +97,36 @@ template <typename T, typename TS, int G>
 __global__ __launch_bounds__(64, MJB_WPS) void k_step(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
   k_step_body<T, TS, G>();
 }
+// Two waves per environment (env_run2, mjb_device.hpp): 128-thread workgroups, one environment each, flat LDS layout (lg).
+template <typename T, typename TS>
+MJB_DEV void k_step2_body() {
+  extern __shared__ __align__(16) char smem[];
+  typedef StepKernArgs<T, TS> KA;
+  const KA MJB_CONST* kp = (const KA MJB_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const DevModel<T> MJB_CONST* mp = (const DevModel<T> MJB_CONST*)kp->mg;
+  const Lay MJB_CONST* lp = (const Lay MJB_CONST*)kp->lg;
+  LayRef L = *lp;
+  MJB_SPEC_ASSUME_LAY(L)
+  T* w = (T*)smem;
+  int* wi = (int*)(w + L.nT);
+  const int env = blockIdx.x;
+  if (env >= kp->d.batch) return;
+  env_run2<T, TS>(mp, lp, kp->d, kp->a, kp->obs, kp->obs_out, w, wi, env, lane, wv);
+}
+template <typename T, typename TS>
+__global__ __launch_bounds__(128, 1) void k_step2(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
+  k_step2_body<T, TS>();
+}
+#if defined(MJB_SPEC_KERNEL) && MJB_SPEC_KERNEL == 3
+}  // namespace mjb
+// specialised two-wave step kernel (mjb_step2_spec_source / mjb_step2_spec_load): sizes and the FLAT layout's offsets pinned, model baked in
+extern "C" __global__ __launch_bounds__(128, 1) void mjb_k_step2_spec(const mjb::DevModel<float>* mg, const mjb::Lay* lg, mjb::DevData<float> d, mjb::DevDebug<float> dbg,
+                                                                       mjb::StepArgs a, mjb::ObsSpecDev obs, float* obs_out) {
+  mjb::k_step2_body<float, float>();
+}
+namespace mjb {
+#endif
 #if defined(MJB_SPEC_KERNEL) && MJB_SPEC_KERNEL == 1
 }  // namespace mjb
 // The one kernel of a specialised translation unit (generated by mjb_model_spec_source, loaded by mjb_spec_load): the fp32
@@ -460,6 +490,8 @@ template <typename T, typename TS>
 hipError_t launch_step(int G, const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, const DevDebug<TS>& dbg, const StepArgs& a,
                        const ObsSpecDev& obs, TS* obs_out, hipStream_t stream);
 template <typename T, typename TS>
+hipError_t launch_step2(const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, const StepArgs& a, const ObsSpecDev& obs, TS* obs_out, hipStream_t stream);
+template <typename T, typename TS>
 int step_blocks_per_cu(int G, const Lay& L);       // resident workgroups of k_step per CU for this layout (<= 0: unknown)
 template <typename T, typename TS>
 hipError_t launch_fd(int G, const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, int ncol, int nv, int nu, int chunk, T eps, T* y, int* valid, hipStream_t stream);
@@ -485,6 +517,16 @@ hipError_t launch_step_g(const DevModel<T>* m, const Lay* Ldev, const Lay& L, co
   int grid = (d.batch + epb - 1) / epb;
   if (a.chunk_steps > 0 && a.grid_blocks > 0 && a.grid_blocks < grid) grid = a.grid_blocks;       // ticket mode: only the resident workgroups
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64), shmem, stream, m, Ldev, d, dbg, a, obs, obs_out);
+  return hipGetLastError();
+}
+template <typename T, typename TS>
+hipError_t launch_step2_impl(const DevModel<T>* m, const Lay* Ldev, const Lay& L, const DevData<TS>& d, const StepArgs& a, const ObsSpecDev& obs, TS* obs_out, hipStream_t stream) {
+  const size_t shmem = (size_t)L.bytes;
+  auto kern = k_step2<T, TS>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return e;
+  DevDebug<TS> none = DevDebug<TS>();
+  hipLaunchKernelGGL(kern, dim3((unsigned)d.batch), dim3(128), shmem, stream, m, Ldev, d, none, a, obs, obs_out);
   return hipGetLastError();
 }
 template <typename T, typename TS, int G>

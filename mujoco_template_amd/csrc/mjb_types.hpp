@@ -94,6 +94,7 @@ struct Lay {
   int rk;             // RK4 scratch: X0 (nq+nv) + F (4*2*nv) + dX (2*nv)
   int nT;             // total T elements
   int i_efc_type, i_efc_id, i_con_pair, i_scal;  // int arrays
+  int i_mail;         // 8 ints: what the two waves of k_step2 tell each other (ncon, nefc, dropped counts, bad-acceleration flag)
   int nI;             // total ints
   int bytes;          // total bytes per environment (rounded to 16)
 };

@@ -625,3 +625,36 @@ def test_specialised_fd_kernel_is_bitwise_identical_to_the_generic_one(world, na
             assert os.path.exists(capi.compile_spec(dm.fd_spec_source()))
     assert np.array_equal(res[False][0], res[None][0]) and np.array_equal(res[False][1], res[None][1])
     assert np.isfinite(res[None][0]).all() and np.abs(res[None][0]).max() > 0
+
+
+@pytest.mark.parametrize("spec", [None, False])
+def test_two_wave_kernel_is_bitwise_identical_to_the_one_wave_kernel(world, spec, monkeypatch):
+    """Small batches are stepped by k_step2 (one environment per 128-thread workgroup, the independent phases of a step side by side on
+    its two wavefronts, flat LDS layout): states, clocks, counters, kinematic outputs and the observation ring equal the one-wave
+    kernel's bit for bit; the policy takes it up to two workgroups per CU and not beyond."""
+    import torch
+
+    cm, om, dm = world("humanoid")
+    B, res = 37, {}
+    for mode in ("0", "policy"):
+        if mode == "0":
+            monkeypatch.setenv("MJB_TWO_WAVE", "0")
+        else:
+            monkeypatch.delenv("MJB_TWO_WAVE")
+        sim = BatchSim(dm, B, dtype="float32", specialize=spec)
+        ospec = sim.make_obs_spec(1 | 2 | 16)
+        out = []
+        for launch, n in enumerate((1, 60, 25)):
+            ring = torch.zeros((max(1, n // 5), B, ospec.dim), dtype=torch.float32, device="cuda")
+            sim.rollout(n, CTRL_RANDOM, seed=6, step0=100 * launch, ctrl_scale=SCALE["humanoid"], obs_spec=ospec, obs_out_ptr=ring.data_ptr(), obs_every=5 if n >= 5 else n)
+            sim.sync()
+            out.append(ring.cpu().numpy())
+        assert sim.schedule_info()["waves_per_env"] == (1 if mode == "0" else 2)
+        cn = sim.counters()
+        res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "ctrl", "time", "xpos", "subtree_com")] + out + [cn[k] for k in ("ncon", "nefc", "solver_niter")]
+    for a, b in zip(res["0"], res["policy"]):
+        assert np.array_equal(a, b)
+    assert res["policy"][10].max() > 0                             # contacts happened
+    big = BatchSim(dm, 600, dtype="float32", specialize=spec)     # more than two workgroups per CU: back to one wave per environment
+    big.rollout(3, CTRL_RANDOM, seed=6)
+    assert big.schedule_info()["waves_per_env"] == 1
