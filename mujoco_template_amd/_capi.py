@@ -491,7 +491,7 @@ class BatchSim:
         _check(load_library().mjb_spec_load(self.ptr, image, len(image)))
         self.specialized = True
         # small batches are stepped by the two-wave kernel where it applies: specialise that one too
-        if self.batch <= 512:
+        if self.batch <= 1024:
             try:
                 src2 = _source_from(load_library().mjb_step2_spec_source, self.ptr)
             except TemplateError:

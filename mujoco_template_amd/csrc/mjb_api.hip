@@ -470,11 +470,11 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
     if (d->two_wave == -1) { const char* e2 = std::getenv("MJB_TWO_WAVE"); d->two_wave = e2 ? (std::atoi(e2) ? 1 : 0) : 2; }
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || ncu < 1) ncu = 256;
-    // every environment must be resident at once and have two SIMDs to itself: the kernel is built for one wave per SIMD
-    // (__launch_bounds__(128, 1)), i.e. two workgroups per CU; measured on the humanoid: x1.14 .. 1.17 up to 512 environments,
-    // x0.6 beyond (profiles/r02_two_wave.log)
+    // every environment must be resident at once: the kernel is built for two waves per SIMD (__launch_bounds__(128, 2)), i.e. four
+    // workgroups per CU.  Measured on the humanoid (profiles/r02_two_wave.log): x1.15 .. 1.18 up to 512 environments (two SIMDs per
+    // environment), x1.12 at 768, x1.09 at 1024, x0.7 beyond (two rounds)
     long wg_per_cu = d->Lf2.bytes > 0 ? (160L * 1024) / d->Lf2.bytes : 0;
-    if (wg_per_cu > 2) wg_per_cu = 2;
+    if (wg_per_cu > 4) wg_per_cu = 4;
     two = d->two_wave == 1 || (d->two_wave == 2 && (long)d->batch <= wg_per_cu * ncu);
   }
   d->last_sched[5] = two ? 1 : 0;

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64, MJB_WPS) void k_step(const DevModel<T>* mg, con
   k_step_body<T, TS, G>();
 }
 // Two waves per environment (env_run2, mjb_device.hpp): 128-thread workgroups, one environment each, flat LDS layout (lg).
+#ifndef MJB_WPS2
+#define MJB_WPS2 2       // waves per SIMD the register budget of k_step2 is sized for: four workgroups per CU (as fast as the 512-VGPR build at <= 512 environments)
+#endif
 template <typename T, typename TS>
 MJB_DEV void k_step2_body() {
   extern __shared__ __align__(16) char smem[];
@@ -115,13 +118,13 @@ MJB_DEV void k_step2_body() {
   env_run2<T, TS>(mp, lp, kp->d, kp->a, kp->obs, kp->obs_out, w, wi, env, lane, wv);
 }
 template <typename T, typename TS>
-__global__ __launch_bounds__(128, 1) void k_step2(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
+__global__ __launch_bounds__(128, MJB_WPS2) void k_step2(const DevModel<T>* mg, const Lay* lg, DevData<TS> d, DevDebug<TS> dbg, StepArgs a, ObsSpecDev obs, TS* obs_out) {
   k_step2_body<T, TS>();
 }
 #if defined(MJB_SPEC_KERNEL) && MJB_SPEC_KERNEL == 3
 }  // namespace mjb
 // specialised two-wave step kernel (mjb_step2_spec_source / mjb_step2_spec_load): sizes and the FLAT layout's offsets pinned, model baked in
-extern "C" __global__ __launch_bounds__(128, 1) void mjb_k_step2_spec(const mjb::DevModel<float>* mg, const mjb::Lay* lg, mjb::DevData<float> d, mjb::DevDebug<float> dbg,
+extern "C" __global__ __launch_bounds__(128, MJB_WPS2) void mjb_k_step2_spec(const mjb::DevModel<float>* mg, const mjb::Lay* lg, mjb::DevData<float> d, mjb::DevDebug<float> dbg,
                                                                        mjb::StepArgs a, mjb::ObsSpecDev obs, float* obs_out) {
   mjb::k_step2_body<float, float>();
 }

@@ -7,7 +7,7 @@ from mujoco_template_amd._capi import BatchSim, DeviceModel, CTRL_RANDOM
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dm = DeviceModel(compile_xml_path(os.path.join(ROOT, "models/humanoid.xml")))
 spec = None if os.environ.get("TW_SPEC", "1") == "1" else False
-for B in [int(x) for x in os.environ.get("TW_B", "1,64,512,1024").split(",")]:
+for B in [int(x) for x in os.environ.get("TW_B", "1,64,256,512,768,1024,1100").split(",")]:
     res = {}
     for two in ("0", "policy"):
         if two == "0": os.environ["MJB_TWO_WAVE"] = "0"

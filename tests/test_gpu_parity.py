@@ -631,7 +631,7 @@ def test_specialised_fd_kernel_is_bitwise_identical_to_the_generic_one(world, na
 def test_two_wave_kernel_is_bitwise_identical_to_the_one_wave_kernel(world, spec, monkeypatch):
     """Small batches are stepped by k_step2 (one environment per 128-thread workgroup, the independent phases of a step side by side on
     its two wavefronts, flat LDS layout): states, clocks, counters, kinematic outputs and the observation ring equal the one-wave
-    kernel's bit for bit; the policy takes it up to two workgroups per CU and not beyond."""
+    kernel's bit for bit; the policy takes it up to four workgroups per CU and not beyond."""
     import torch
 
     cm, om, dm = world("humanoid")
@@ -655,6 +655,6 @@ def test_two_wave_kernel_is_bitwise_identical_to_the_one_wave_kernel(world, spec
     for a, b in zip(res["0"], res["policy"]):
         assert np.array_equal(a, b)
     assert res["policy"][10].max() > 0                             # contacts happened
-    big = BatchSim(dm, 600, dtype="float32", specialize=spec)     # more than two workgroups per CU: back to one wave per environment
+    big = BatchSim(dm, 1100, dtype="float32", specialize=spec)    # more than four workgroups per CU: back to one wave per environment
     big.rollout(3, CTRL_RANDOM, seed=6)
     assert big.schedule_info()["waves_per_env"] == 1
