@@ -230,6 +230,14 @@ def main() -> None:
     counters = env.data.counters()
     kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     steps_per_launch = [n for _, _, n in events]
+    # an event pair occasionally spans a stall of the whole device (seen once: 44 ms around a 1.9 ms launch whose rocprof dispatch was
+    # 1.9 ms): launches slower than 3x the median are left out of the roofline average and counted
+    all_ms = [round(float(t), 3) for t in kernel_ms]
+    med_ms = float(np.median(kernel_ms))
+    outliers = [k for k, t in enumerate(kernel_ms) if t > 3.0 * med_ms]
+    if outliers and len(outliers) < len(kernel_ms):
+        kernel_ms = [t for k, t in enumerate(kernel_ms) if k not in outliers]
+        steps_per_launch = [n for k, n in enumerate(steps_per_launch) if k not in outliers]
     ranks_seen = dist.get_world_size() if distributed else 1
     shards = [[env0, count]]
     if distributed:
@@ -284,7 +292,7 @@ def main() -> None:
                        "work_schedule": sim.schedule_info()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("mjb_k_step_spec (k_step<float,float,%d> with the model's sizes/offsets folded in)" if sim.specialized else "mjb::k_step<float,float,%d>") % sim.lanes,
-                         "traffic_source": traffic_source, "launch_steps": avg_steps, "launches_timed": len(kernel_ms), "launches_in_timed_region": in_region,
+                         "traffic_source": traffic_source, "launch_steps": avg_steps, "launches_timed": len(kernel_ms), "launches_left_out_as_outliers": len(outliers), "launch_ms_all": all_ms, "launches_in_timed_region": in_region,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_env_step": bytes_step, "obs_bytes_per_env": bytes_obs,
                          "note": "fused step is VALU/LDS-latency bound by construction (SURVEY.md §8d); see DESIGN.md for VALU/LDS counters"},
             "solver": {"mean_nefc_last_step": float(counters["nefc"].mean()), "max_nefc_last_step": int(counters["nefc"].max()),
