@@ -224,7 +224,7 @@ def main() -> None:
     in_region = len(events)
     # the roofline's launch duration is an average over >= 5 launches: when the timed region was fewer (a short --steps run is ONE
     # fused launch), more launches of the same length follow it here - they count for `roofline` only, never for `value`
-    while len(events) < 5:
+    while len(events) < 6:                                        # one spare: the last event pair of a burst of short launches can read long (below)
         run(events[0][2], events)
     torch.cuda.synchronize()
     counters = env.data.counters()
