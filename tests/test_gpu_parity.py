@@ -650,6 +650,9 @@ def test_two_wave_kernel_is_bitwise_identical_to_the_one_wave_kernel(world, spec
             sim.sync()
             out.append(ring.cpu().numpy())
         assert sim.schedule_info()["waves_per_env"] == (1 if mode == "0" else 2)
+        if mode == "policy":                                       # the source build() pre-compiles from the model alone is the data object's: a GPU box compiles nothing
+            import mujoco_template_amd._capi as capi
+            assert capi._source_from(capi.load_library().mjb_step2_spec_source, sim.ptr) == dm.step2_spec_source()
         cn = sim.counters()
         res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "ctrl", "time", "xpos", "subtree_com")] + out + [cn[k] for k in ("ncon", "nefc", "solver_niter")]
     for a, b in zip(res["0"], res["policy"]):
