@@ -2053,11 +2053,40 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   // warmstart(): best of (qacc_warmstart, qacc_smooth) as the starting point.  The unconstrained point is evaluated FIRST so
   // that in the common case (the warm start wins) Ma / jar / force are already those of the chosen point: two cost
   // evaluations instead of three; same costs, same decision (warm start only if strictly cheaper).
-  T cost = solver_cost<T, G>(c, qas, true);
+  // Both candidates in ONE pass over the stacked [M; J] (every matrix element read once, two FMAs): M x / J x - aref of the
+  // unconstrained point go to Ma / jar, those of the previous solution to Mv / jv (free until the first line search); the winner's
+  // are then where the iterations expect them.  Per-row arithmetic and reduction order are those of solver_cost(): same costs, same decision.
+  T cost;
   {
-    const T cost_ws = solver_cost<T, G>(c, ws, true);
-    if (cost_ws < cost) { cost = cost_ws; for (int i = lane; i < nv; i += G) qacc[i] = ws[i]; }
-    else { cost = solver_cost<T, G>(c, qas, true); for (int i = lane; i < nv; i += G) qacc[i] = qas[i]; }
+    T *aref = w + L.efc_aref;
+    T pa = 0, pb = 0;
+    const VecLds<T> xa{qas}, xb{ws};
+    for (int rho = lane; rho < nv + nefc; rho += G) {
+      const bool ism = rho < nv;
+      const int r = ism ? rho : rho - nv;
+      const T* row = ism ? M + r * nv : J + r * nv;
+      T sa = dot_lds(row, 1, xa, nv), sb = dot_lds(row, 1, xb, nv);
+      if (ism) {
+        Ma[r] = sa; Mv[r] = sb;
+        pa += (T)0.5 * (sa - qs[r]) * (qas[r] - qas[r]);
+        pb += (T)0.5 * (sb - qs[r]) * (ws[r] - qas[r]);
+      } else {
+        sa -= aref[r]; sb -= aref[r];
+        jar[r] = sa; jv[r] = sb;
+        if (sa < 0) pa += (T)0.5 * D[r] * sa * sa;
+        if (sb < 0) pb += (T)0.5 * D[r] * sb * sb;
+      }
+    }
+    const T cost_a = gsum<T, G>(pa), cost_b = gsum<T, G>(pb);
+    gsync<G>();
+    const bool wsw = cost_b < cost_a;                            // warm start only if strictly cheaper
+    cost = wsw ? cost_b : cost_a;
+    for (int i = lane; i < nv; i += G) { qacc[i] = wsw ? ws[i] : qas[i]; if (wsw) Ma[i] = Mv[i]; }
+    for (int r = lane; r < nefc; r += G) {
+      const T sj = wsw ? jv[r] : jar[r];
+      if (wsw) jar[r] = sj;
+      force[r] = sj < 0 ? -D[r] * sj : (T)0;
+    }
   }
   gsync<G>();
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
