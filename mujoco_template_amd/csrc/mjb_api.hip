@@ -80,6 +80,7 @@ struct mjbData {
   Lay* Lf2_dev = nullptr;
   hipModule_t spec2_mod = nullptr;          // per-model specialised two-wave kernel (mjb_step2_spec_load)
   hipFunction_t spec2_fn = nullptr;
+  int ncu = 0;                              // CUs of the device (queried once)
   int two_wave = -1;                        // MJB_TWO_WAVE: 0 never, 1 whenever it applies, -1 (default) the policy in launch()
   int up_disable = -1, up_iter = -1; double up_tol = -1;
   DevData<float> df;
@@ -355,6 +356,19 @@ std::string baked_model_source(const HostModel& h, int ncon_max, int nefc_max, b
     if (i % 8 == 7) init += "\n ";
   }
   decl += " };\n"; init += " };\n";
+  {
+    // every emitted table must be referenced by exactly one pointer word of the image (a data word that happens to look like a token,
+    // or a table the struct does not point at, would make the image wrong): otherwise no baked model - the kernel reads the device copy
+    std::vector<int> seen((size_t)ea.n, 0);
+    bool ok = true;
+    for (size_t i = 0; i < nw && ok; i++)
+      if ((wv[i] >> 32) == (EmitAlloc::TOKEN >> 32)) {
+        const unsigned long long k = (wv[i] - EmitAlloc::TOKEN) / 16 - 1;
+        if (k >= (unsigned long long)ea.n || (wv[i] - EmitAlloc::TOKEN) % 16 != 0 || seen[(size_t)k]++) ok = false;
+      }
+    for (int k = 0; k < ea.n && ok; k++) if (seen[(size_t)k] != 1) ok = false;
+    if (!ok) return std::string("// (model not baked in: the DevModel image did not map one-to-one onto the emitted tables)\n");
+  }
   std::string s = "#include \"mjb_types.hpp\"\n// the model as constant data of this translation unit (tables, then the DevModel image)\n";
   s += ea.tables_source() + decl + init;
   s += std::string("static_assert(sizeof(MjbBakedModel) == sizeof(mjb::DevModel<") + tname + ">), \"baked model image\");\n";
@@ -468,8 +482,8 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
   bool two = false;
   if (a.mode == 0 && !debug && d->dtype == MJB_F32 && d->Lf2.bytes > 0 && a.chunk_steps == 0) {
     if (d->two_wave == -1) { const char* e2 = std::getenv("MJB_TWO_WAVE"); d->two_wave = e2 ? (std::atoi(e2) ? 1 : 0) : 2; }
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || ncu < 1) ncu = 256;
+    if (d->ncu <= 0 && (hipDeviceGetAttribute(&d->ncu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || d->ncu < 1)) d->ncu = 256;
+    const int ncu = d->ncu;
     // every environment must be resident at once: the kernel is built for two waves per SIMD (__launch_bounds__(128, 2)), i.e. four
     // workgroups per CU.  Measured on the humanoid (profiles/r02_two_wave.log): x1.15 .. 1.18 up to 512 environments (two SIMDs per
     // environment), x1.12 at 768, x1.09 at 1024, x0.7 beyond (two rounds)

@@ -106,6 +106,12 @@ def test_spec_scheduler_rule_and_private_cache(tmp_path, monkeypatch):
     for name in ("humanoid", "drone2", "cartpole"):               # models with real constraint rows: the scheduler that was measured to pay
         assert spec_scheduler(DeviceModel(mjcf.compile_xml_path(MODELS[name])).spec_source()) == "iterative-ilp"
     assert spec_scheduler(DeviceModel(mjcf.compile_xml_path(MODELS["pendulum"])).spec_source()) is None     # 2 rows at most: tiny kernel
+    # the specialised translation units carry the model itself (tables + DevModel image) and the float64 / two-wave variants exist
+    hum = DeviceModel(mjcf.compile_xml_path(MODELS["humanoid"]))
+    for src, kind, ctype in ((hum.spec_source(), 1, "float"), (hum.fd_spec_source(), 2, "double"), (hum.step2_spec_source(), 3, "float")):
+        assert f"#define MJB_SPEC_KERNEL {kind}" in src and "#define MJB_SPEC_BAKED" in src and f"static const __constant__ {ctype} mjb_tab_" in src
+        assert "not baked" not in src
+    assert DeviceModel(mjcf.compile_xml_path(MODELS["cartpole"])).step2_spec_source() is None            # packed kernels: one wave per several environments
     base_src = DeviceModel(mjcf.compile_xml_string(BASE_XML)).spec_source()
     assert "#define MJB_SPEC_G 8" in base_src and spec_scheduler(base_src) is None
     assert os.path.exists(compile_spec(base_src))                 # the crashing case compiles under the rule (cross-compile only)
