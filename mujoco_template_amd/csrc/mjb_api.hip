@@ -202,7 +202,7 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   rc |= dev_alloc(d, &s.qfrc_inverse, B * h.nv); rc |= dev_alloc(d, &s.actuator_moment, B * h.nu * h.nv);
   rc |= dev_alloc(d, &s.counters, B * CNT_N); rc |= dev_alloc(d, &s.flags, 1);
   rc |= dev_alloc(d, &s.sched, 1);
-  if (sizeof(TS) == 4) rc |= dev_alloc(d, &s.xfer, B * (size_t)(h.nq + 3 * h.nv + 2)); else s.xfer = nullptr;
+  s.xfer = nullptr;                                             // hand-over buffer of the ticket map: allocated by the first launch that needs it
   rc |= dev_alloc(d, &s.prof, (size_t)PH_N + 4 * B);        // + per-environment timeline records of the -DMJB_TIMELINE diagnostic kernel
   if (rc) return -1;
   auto& A = d->arrays;
@@ -460,6 +460,10 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
   choose_schedule(d, a);
   if (a.chunk_steps > 0) {
     if (d->dtype != MJB_F32 || a.nstep >= (1 << 20) - 2) a.chunk_steps = 0;     // hand-over words are (fp32, tag) pairs; 20 bits of step index in the tag
+  }
+  if (a.chunk_steps > 0 && !d->df.xfer) {
+    const HostModel& hm = d->model->h;
+    if (dev_alloc(d, &d->df.xfer, (size_t)d->batch * (size_t)(hm.nq + 3 * hm.nv + 2))) { d->df.xfer = nullptr; a.chunk_steps = 0; }   // no memory: static map
   }
   if (a.chunk_steps > 0) chunk_plan_counts(a.nstep, a.chunk_steps, a.nuniform, a.nchunk);
   if (a.mode == 0) {
