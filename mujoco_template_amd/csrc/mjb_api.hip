@@ -1289,14 +1289,19 @@ int mjb_host_view(mjbData* d, const char* name, double** host_ptr, long* per_env
   return fail(MJB_ERR_ARG, std::string("no host mirror for array: ") + name);
 }
 
+// Small blocks (a few environments: the reference's batch-1 loops) skip the staging copy: the pack / unpack kernels read and write
+// the pinned host block itself (device-visible, unified addressing) - two runtime calls less per host-driven step.
+static bool mirror_zero_copy(const mjbData* d) { return d->mirror_off[6] + 1 <= 8192; }
+
 static int mirror_pull(mjbData* d) {
   const HostModel& h = d->model->h;
   const long total = (long)d->mirror_off[6];
   const unsigned grid = (unsigned)((total + 255) / 256);
-  if (d->dtype == MJB_F32) hipLaunchKernelGGL(k_mirror_pack<float>, dim3(grid), dim3(256), 0, d->stream, d->df, h.nq, h.nv, h.nu, d->mirror_dev, total);
-  else hipLaunchKernelGGL(k_mirror_pack<double>, dim3(grid), dim3(256), 0, d->stream, d->dd, h.nq, h.nv, h.nu, d->mirror_dev, total);
+  double* dst = mirror_zero_copy(d) ? d->mirror_host : d->mirror_dev;
+  if (d->dtype == MJB_F32) hipLaunchKernelGGL(k_mirror_pack<float>, dim3(grid), dim3(256), 0, d->stream, d->df, h.nq, h.nv, h.nu, dst, total);
+  else hipLaunchKernelGGL(k_mirror_pack<double>, dim3(grid), dim3(256), 0, d->stream, d->dd, h.nq, h.nv, h.nu, dst, total);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(d->mirror_host, d->mirror_dev, (size_t)(total + 1) * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  if (dst == d->mirror_dev) HIPCHK(hipMemcpyAsync(d->mirror_host, d->mirror_dev, (size_t)(total + 1) * sizeof(double), hipMemcpyDeviceToHost, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   return MJB_OK;
 }
@@ -1309,11 +1314,12 @@ static int mirror_push(mjbData* d, int mask) {
   while (!((mask >> lo) & 1)) lo++;
   while (!((mask >> hi) & 1)) hi--;
   const size_t a = d->mirror_off[lo], b = d->mirror_off[hi + 1];       // one contiguous span covering the edited fields
-  HIPCHK(hipMemcpyAsync(d->mirror_dev + a, d->mirror_host + a, (b - a) * sizeof(double), hipMemcpyHostToDevice, d->stream));
+  const double* src = mirror_zero_copy(d) ? d->mirror_host : d->mirror_dev;
+  if (src == d->mirror_dev) HIPCHK(hipMemcpyAsync(d->mirror_dev + a, d->mirror_host + a, (b - a) * sizeof(double), hipMemcpyHostToDevice, d->stream));
   const long total = (long)d->mirror_off[6];
   const unsigned grid = (unsigned)((total + 255) / 256);
-  if (d->dtype == MJB_F32) hipLaunchKernelGGL(k_mirror_unpack<float>, dim3(grid), dim3(256), 0, d->stream, d->df, h.nq, h.nv, h.nu, (const double*)d->mirror_dev, total, mask);
-  else hipLaunchKernelGGL(k_mirror_unpack<double>, dim3(grid), dim3(256), 0, d->stream, d->dd, h.nq, h.nv, h.nu, (const double*)d->mirror_dev, total, mask);
+  if (d->dtype == MJB_F32) hipLaunchKernelGGL(k_mirror_unpack<float>, dim3(grid), dim3(256), 0, d->stream, d->df, h.nq, h.nv, h.nu, src, total, mask);
+  else hipLaunchKernelGGL(k_mirror_unpack<double>, dim3(grid), dim3(256), 0, d->stream, d->dd, h.nq, h.nv, h.nu, src, total, mask);
   HIPCHK(hipGetLastError());
   return MJB_OK;
 }
@@ -1340,8 +1346,22 @@ int mjb_step_host(mjbData* d, int nstep, int field_mask) {
   int rc = ensure_mirror(d);
   if (rc != MJB_OK) return rc;
   HIPCHK(hipSetDevice(d->device));
-  if ((rc = mirror_push(d, field_mask)) != MJB_OK) return rc;
   ObsSpecDev none; std::memset(&none, 0, sizeof(none));
+  if (nstep > 0 && mirror_zero_copy(d) && d->dtype == MJB_F32) {
+    // small batches: ONE launch - the step kernel reads the edited fields from the pinned block and writes the new state back into it
+    StepArgs a = make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0);
+    a.mirror = d->mirror_host; a.mirror_mask = field_mask & 63;
+    double* flagword = d->mirror_host + d->mirror_off[6];
+    if ((rc = launch(d, a, none, nullptr, false)) != MJB_OK) return rc;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (*flagword < 0) {                                       // some environment raised an engine flag: fetch the sticky word
+      int fl = 0;
+      HIPCHK(hipMemcpy(&fl, d->df.flags, sizeof(int), hipMemcpyDeviceToHost));
+      *flagword = (double)fl;
+    }
+    return MJB_OK;
+  }
+  if ((rc = mirror_push(d, field_mask)) != MJB_OK) return rc;
   if (nstep > 0 && (rc = launch(d, make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0), none, nullptr, false)) != MJB_OK) return rc;
   if (nstep == 0 && (rc = launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, false)) != MJB_OK) return rc;   // mj_forward
   return mirror_pull(d);

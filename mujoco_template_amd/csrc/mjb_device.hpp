@@ -2455,6 +2455,34 @@ template <typename T, typename TS, int G> MJB_DEV void write_obs(const Ctx<T>& c
 // ---------------------------------------------------------------------------
 // the per-environment driver: load -> nstep x (ctrl, forward, integrate) -> store
 // ---------------------------------------------------------------------------
+// Host mirror inside the step kernel (StepArgs::mirror, small batches): layout of mjb_host_view - qpos | qvel | ctrl | qacc |
+// qacc_warmstart | time, each [batch, n] float64, then one word of engine flags.
+template <typename T, int G, typename MRef>
+MJB_DEV void mirror_in(MRef m, LayRef L, T* w, const double* mir, int mask, int env, int batch, int lane, double& time) {
+  const size_t B = (size_t)batch, nq = m.nq, nv = m.nv, nu = m.nu;
+  const double *mq = mir + (size_t)env * nq, *mv = mir + B * nq + (size_t)env * nv, *mc = mir + B * (nq + nv) + (size_t)env * nu;
+  const double *ma = mir + B * (nq + nv + nu) + (size_t)env * nv, *mw = ma + B * nv, *mt = mir + B * (nq + 3 * nv + nu) + env;
+  if (mask & 1) for (int i = lane; i < (int)nq; i += G) w[L.qpos + i] = (T)mq[i];
+  if (mask & 2) for (int i = lane; i < (int)nv; i += G) w[L.qvel + i] = (T)mv[i];
+  if (mask & 4) for (int i = lane; i < (int)nu; i += G) w[L.ctrl + i] = (T)mc[i];
+  if (mask & 8) for (int i = lane; i < (int)nv; i += G) w[L.qacc + i] = (T)ma[i];
+  if (mask & 16) for (int i = lane; i < (int)nv; i += G) w[L.qacc_ws + i] = (T)mw[i];
+  if (mask & 32) time = *mt;
+}
+template <typename T, int G, typename MRef>
+MJB_DEV void mirror_out(MRef m, LayRef L, const T* w, double* mir, int env, int batch, int lane, double time, int fl) {
+  const size_t B = (size_t)batch, nq = m.nq, nv = m.nv, nu = m.nu;
+  double *mq = mir + (size_t)env * nq, *mv = mir + B * nq + (size_t)env * nv, *mc = mir + B * (nq + nv) + (size_t)env * nu;
+  double *ma = mir + B * (nq + nv + nu) + (size_t)env * nv, *mw = ma + B * nv, *mt = mir + B * (nq + 3 * nv + nu) + env;
+  for (int i = lane; i < (int)nq; i += G) mq[i] = (double)w[L.qpos + i];
+  for (int i = lane; i < (int)nv; i += G) { mv[i] = (double)w[L.qvel + i]; ma[i] = (double)w[L.qacc + i]; mw[i] = (double)w[L.qacc_ws + i]; }
+  for (int i = lane; i < (int)nu; i += G) mc[i] = (double)w[L.ctrl + i];
+  if (lane == 0) {
+    *mt = time;
+    if (fl) mir[B * (nq + 3 * nv + nu + 1)] = -1.0;           // "engine flags changed": the host fetches the sticky word (no read-modify-write over the bus)
+  }
+}
+
 // Hand-over of an environment between the chunks of ONE launch (ticket mode of k_step, mjb_kernels.hpp): the wave that ends chunk
 // k - 1 and the wave that starts chunk k may sit on different XCDs, so the words travel as 64-bit (value, tag) pairs written and
 // read with agent-scope relaxed atomics (single-copy atomic, coherent across the XCDs' L2s): tag = tagbase + step index is unique
@@ -2523,6 +2551,9 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
   }
   for (int i = lane; i < nu; i += G) w[L.ctrl + i] = a.ctrl_mode == CTRL_ZERO ? (T)0 : (T)d.ctrl[(size_t)env * nu + i];
   for (int i = lane; i < nv * nv; i += G) w[L.M + i] = 0;       // structural zeros of the mass matrix (crb_factor fills the rest)
+#ifndef MJB_HOST_EMU
+  if (a.mirror && a.mirror_mask) mirror_in<T, G>(m, L, w, a.mirror, a.mirror_mask, env, d.batch, lane, time);
+#endif
   int badqpos = 0, badqvel = 0, badqacc = 0;
   gsync<G>();
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
@@ -2623,12 +2654,15 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
     d.qacc[(size_t)env * nv + i] = (TS)w[L.qacc + i];
     d.qacc_warmstart[(size_t)env * nv + i] = (TS)w[L.qacc_ws + i];
   }
-  if (a.ctrl_mode != CTRL_KEEP) for (int i = lane; i < nu; i += G) d.ctrl[(size_t)env * nu + i] = (TS)w[L.ctrl + i];
+  if (a.ctrl_mode != CTRL_KEEP || (a.mirror && (a.mirror_mask & 4))) for (int i = lane; i < nu; i += G) d.ctrl[(size_t)env * nu + i] = (TS)w[L.ctrl + i];
   if (lane == 0) {
     d.time[env] = time;
     int* cn = d.counters + (size_t)env * CNT_N;
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
   }
+#ifndef MJB_HOST_EMU
+  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0));
+#endif
   if (a.write_kin) {
     for (int i = lane; i < 3 * m.nbody; i += G) {
       d.xpos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xpos + i];
@@ -2702,6 +2736,7 @@ MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, 
     for (int i = lane; i < nv * nv; i += G) w[L.M + i] = 0;     // structural zeros of the mass matrix
     if (lane < 8) mail[lane] = 0;
     time = d.time[env];
+    if (a.mirror && a.mirror_mask) mirror_in<T, G>(m, L, w, a.mirror, a.mirror_mask, env, d.batch, lane, time);
   }
   __syncthreads();
   for (int s = 0; s < a.nstep; s++) {
@@ -2768,13 +2803,14 @@ MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, 
     d.time[env] = time;
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
   }
+  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (mail[2] ? 1 : 0) | (mail[3] ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0));
   for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
   for (int i = lane; i < nv; i += G) {
     d.qvel[(size_t)env * nv + i] = (TS)w[L.qvel + i];
     d.qacc[(size_t)env * nv + i] = (TS)w[L.qacc + i];
     d.qacc_warmstart[(size_t)env * nv + i] = (TS)w[L.qacc_ws + i];
   }
-  if (a.ctrl_mode != CTRL_KEEP) for (int i = lane; i < nu; i += G) d.ctrl[(size_t)env * nu + i] = (TS)w[L.ctrl + i];
+  if (a.ctrl_mode != CTRL_KEEP || (a.mirror && (a.mirror_mask & 4))) for (int i = lane; i < nu; i += G) d.ctrl[(size_t)env * nu + i] = (TS)w[L.ctrl + i];
   if (a.write_kin) {
     for (int i = lane; i < 3 * m.nbody; i += G) {
       d.xpos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xpos + i];

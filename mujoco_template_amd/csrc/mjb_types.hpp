@@ -146,6 +146,11 @@ struct StepArgs {
   // optional ctrl noise of that law (reference lqr.py:160-165): + std[a] * table[(step + env * stride) mod nsteps][a] before the clip
   const void *fb_noise_std, *fb_noise_tab;
   int fb_nsteps, fb_env_stride;
+  // host-driven steps of small batches (mjb_step_host): the pinned host mirror block itself, device-visible; the kernel reads the
+  // fields the host edited (mirror_mask: bit k = field k of qpos qvel ctrl qacc qacc_warmstart time) from it and writes all six
+  // back at the end - no staging copies, no pack / unpack kernels.  nullptr otherwise.
+  double* mirror;
+  int mirror_mask;
   int fair_bit;          // >0: alternate the issue priority of a SIMD's waves by this bit of the 100 MHz clock (env_run); 0 = leave the hardware's age order
   unsigned ticket_base;  // ticket mode: value of d.sched[0] when this launch starts (the counter is not reset between launches)
   unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ the step index at which the hand-over happens), unique among the launches that could still be in the buffer
