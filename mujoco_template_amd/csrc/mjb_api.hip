@@ -290,8 +290,8 @@ struct EmitAlloc {
   // table a member of ONE struct - a single base address, an extra address add per lane-indexed read, far fewer address registers.
   // Measured (scripts/gpu_spec_check.py, same box, B = 4096, M env-steps/s; pointer hops / struct / arrays): humanoid 41.7 / 43.1 /
   // 43.4, drone2 178 / 193 / 218, cart-pole 215 / 230 / 248.  The humanoid kernel (256 VGPRs) spills 61 VGPRs to scratch with the
-  // array form (one spill store per env-step: HBM write traffic 0.15 -> 1.2 GB per 1000-step launch) and none with the struct form;
-  // it is still 0.8 % faster with the arrays.
+  // array form (spill stores around the ticket loop, ~7 KB per environment and chunk switch: HBM write traffic 0.15 -> 1.2 GB per
+  // 1000-step launch) and far fewer with the struct form; it is still 2 % faster with the arrays (4 % on the two-wave kernel).
   bool as_struct = false;
   std::string text, decl, init;
   int n = 0;
