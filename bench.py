@@ -138,7 +138,10 @@ def main() -> None:
         raise SystemExit("--all-ranks-device0 needs --backend gloo (RCCL refuses two ranks on one GPU)")
     device = 0 if (ws == 1 or args.all_ranks_device0) else local
     torch.cuda.set_device(device)
-    distributed = init_process_group(args.backend) if ws > 1 else False
+    # under torchrun with ONE rank the process group is still set up and every collective below is issued (one-rank communicator):
+    # the one-GPU rehearsal of the nccl path; `python bench.py` from a plain shell (no RANK) runs without torch.distributed as before
+    single = ws == 1 and "RANK" in os.environ
+    distributed = init_process_group(args.backend, single_rank=single) if (ws > 1 or single) else False
 
     xml = {"humanoid": "models/humanoid.xml", "cartpole": "models/cartpole.xml", "drone2": "models/drone2/scene.xml",
            "pendulum": "models/pendulum.xml"}[args.model]
@@ -174,12 +177,12 @@ def main() -> None:
             if events is not None:
                 e1.record()
                 events.append((e0, e1, n))
-            all_gather_obs(obs, counts=counts)             # RCCL all-gather of the ObservationExtractor output (sizes known: no size exchange)
+            all_gather_obs(obs, counts=counts, single_rank=single)             # RCCL all-gather of the ObservationExtractor output (sizes known: no size exchange)
             done += n
 
     def barrier() -> None:
         if distributed:
-            dist.barrier()
+            dist.barrier(device_ids=[device]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     run(args.warmup)
@@ -308,7 +311,7 @@ def main() -> None:
             out["host_loop"] = host_loop(os.path.join(ROOT, xml), scale, device, global_batch)
         print(json.dumps(out), flush=True)
     if distributed:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

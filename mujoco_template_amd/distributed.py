@@ -25,13 +25,17 @@ def shard_range(global_batch: int, rank: int, world_size: int) -> tuple[int, int
     return env0, count
 
 
-def init_process_group(backend: str | None = None) -> bool:
-    """Initialise torch.distributed from the env when WORLD_SIZE > 1.  Returns True if initialised."""
+def init_process_group(backend: str | None = None, single_rank: bool = False) -> bool:
+    """Initialise torch.distributed from the env when WORLD_SIZE > 1.  Returns True if initialised.
+
+    ``single_rank=True`` also initialises a ONE-rank group when the torchrun environment is present (RANK set): the rehearsal of the
+    ``nccl`` code path on a one-GPU box (communicator setup, the collective on the launch stream, the barrier / reductions of the bench).
+    """
     import torch
     import torch.distributed as dist
 
     rank, ws, local = world()
-    if ws <= 1:
+    if ws <= 1 and not (single_rank and "RANK" in os.environ):
         return False
     if dist.is_initialized():
         return True
@@ -44,18 +48,19 @@ def init_process_group(backend: str | None = None) -> bool:
     return True
 
 
-def all_gather_obs(local_obs, global_batch: int | None = None, counts=None):
+def all_gather_obs(local_obs, global_batch: int | None = None, counts=None, single_rank: bool = False):
     """All-gather ``[..., b_local, dim]`` blocks along the batch axis (axis -2) into ``[..., B, dim]``.
 
     Equal shards use one ``all_gather_into_tensor`` (a single RCCL collective); ragged shards
     fall back to ``all_gather`` with padding.  Without an initialised process group this is the identity.
     ``counts`` (per-rank shard sizes, e.g. from ``shard_range``) skips the size exchange and its host sync.
     With the ``gloo`` backend CUDA blocks are staged through the host (rehearsals on one GPU).
+    ``single_rank=True`` issues the collective even in a one-rank group (one-GPU rehearsal of the ``nccl`` path) instead of returning early.
     """
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not single_rank):
         return local_obs
     ws = dist.get_world_size()
     x = local_obs.movedim(-2, 0).contiguous()                  # [b_local, ..., dim]

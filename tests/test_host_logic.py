@@ -134,6 +134,37 @@ def test_gloo_world_size_2_all_gather_obs(tmp_path):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
 
 
+def test_gloo_single_rank_group_issues_the_collective(tmp_path):
+    """single_rank=True (the one-GPU rehearsal switch of bench.py under torchrun): a ONE-rank group is initialised and the all-gather is
+    really issued instead of short-circuiting; without RANK in the environment nothing is initialised."""
+    script = tmp_path / "worker1.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from mujoco_template_amd.distributed import init_process_group, all_gather_obs\n"
+        "assert not init_process_group('gloo')                 # ws == 1, no single_rank: nothing initialised\n"
+        "assert init_process_group('gloo', single_rank=True) and dist.get_world_size() == 1\n"
+        "calls = []\n"
+        "real = dist.all_gather_into_tensor\n"
+        "dist.all_gather_into_tensor = lambda out, x: (calls.append(1), real(out, x))[1]\n"
+        "x = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)\n"
+        "assert all_gather_obs(x, counts=[3]) is x and not calls\n"
+        "out = all_gather_obs(x, counts=[3], single_rank=True)\n"
+        "assert calls == [1] and out is not x and torch.equal(out, x)\n"
+        "dist.destroy_process_group()\n"
+        f"open(os.path.join({str(tmp_path)!r}, 'ok1'), 'w').write('ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "ok1").exists()
+    env.pop("RANK")
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
+                        "from mujoco_template_amd.distributed import init_process_group as f; assert not f('gloo', single_rank=True)"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_recorder_schema_and_trajectory_logger(tmp_path):
     """CSV schema of the reference's StateControlRecorder (logging.py:81-178): joint-major qpos/qvel columns with the
     per-joint-type component suffixes, ctrl columns by actuator name, probes last; TrajectoryLogger row-length check."""
