@@ -151,6 +151,57 @@ class MjModel:
     def compiled(self) -> CompiledModel:
         return self._c
 
+    # named accessors ---------------------------------------------------------------
+    # ``model.body("torso").id`` / ``model.joint(j).name``: the slice of the ``mujoco`` bindings' named-access API the reference
+    # uses (``examples/humanoid/controllers/lqr.py:93-95,222``).  Names resolve through the C ABI (mjb_model_name2id / id2name).
+    def _named(self, objtype: int, count: int, kind: str, key: "int | str") -> "_NamedView":
+        if isinstance(key, str):
+            idx = mj_name2id(self, objtype, key)
+            if idx < 0:
+                valid = [n for n in (mj_id2name(self, objtype, i) for i in range(count)) if n]
+                raise KeyError(f"Invalid name '{key}'. Valid names: {valid}")
+            return _NamedView(int(idx), key)
+        idx = int(key)
+        if not 0 <= idx < count:
+            raise IndexError(f"{kind} id {idx} out of range [0, {count})")
+        return _NamedView(idx, mj_id2name(self, objtype, idx) or "")
+
+    def body(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_BODY, self.nbody, "body", key)
+
+    def joint(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_JOINT, self.njnt, "joint", key)
+
+    def geom(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_GEOM, self.ngeom, "geom", key)
+
+    def site(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_SITE, self.nsite, "site", key)
+
+    def tendon(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_TENDON, self.ntendon, "tendon", key)
+
+    def actuator(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_ACTUATOR, self.nu, "actuator", key)
+
+    def sensor(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_SENSOR, self.nsensor, "sensor", key)
+
+    def key(self, key: "int | str") -> "_NamedView":
+        return self._named(mjtObj.mjOBJ_KEY, self.nkey, "keyframe", key)
+
+
+class _NamedView:
+    """What ``model.body(...)`` and friends return: the element's ``id`` and ``name``."""
+
+    __slots__ = ("id", "name")
+
+    def __init__(self, idx: int, name: str):
+        self.id, self.name = idx, name
+
+    def __repr__(self) -> str:
+        return f"<_NamedView id={self.id} name={self.name!r}>"
+
 
 # ----------------------------------------------------------------------------------
 # data

@@ -627,3 +627,31 @@ def test_c_abi_allgather_obs_runs_ncclallgather_on_a_one_rank_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_humanoid_balances_on_one_leg_under_the_tutorial_lqr_and_fp32_tracks_float64():
+    """The reference's humanoid example end to end (examples/humanoid/controllers/lqr.py:34-170), with the recipe of DeepMind's LQR tutorial
+    that example transcribes (the reference keeps its text as LQR.txt:159-323,354-417): height sweep by batched ``mj_inverse``, set-point
+    ``ctrl0``, ``(A, B)`` from ``linearize_discrete``, COM-over-foot cost from the Jacobians, ``K`` from scipy's DARE, then the law with the
+    tutorial's seed-1 smoothed ctrl noise evaluated inside the fused kernel.  Behavioural known answer of real MuJoCo on this very XML and
+    noise sequence: the humanoid keeps its balance for the 12 s.  Closed loop = not chaotic, so BASELINE's drift bound applies as written:
+    fp32 vs float64 kernels stay within 1e-4 over 1000 steps (measured 6e-6; 1.1e-4 over all 2400 steps, contacts active throughout)."""
+    scipy = pytest.importorskip("scipy")  # noqa: F841
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gpu_humanoid_lqr", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "gpu_humanoid_lqr.py"))
+    lqr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lqr)
+    model = mj.MjModel.from_xml_path(MODELS["humanoid"])
+    assert model.body("torso").id == 1 and model.joint(3).name == "abdomen_x"            # the named accessors the example uses (lqr.py:93-95,222)
+    with pytest.raises(KeyError):
+        model.body("no_such_body")
+    d = lqr.design(model, lqr.TUTORIAL, verbose=False)
+    assert d["bal"].tolist() == [7, 8, 15, 17, 18, 19, 20]                                 # abdomen_y/x + left hip_x/y, knee, ankle_y/x
+    assert -1e-3 < d["offset"] < 0 and abs(d["forces"][-1] - 40.8446 * 9.81) < 0.05        # +1 mm: foot off the floor, residual = the weight
+    assert np.abs(d["ctrl0"]).max() < 1.0 and abs(d["rho"] - 1.0) < 1e-6                   # set-point inside ctrlrange; marginal translation modes only
+    assert float(np.abs(np.linalg.eigvals(d["A"])).max()) > 1.03                           # open loop: unstable (it falls without feedback)
+    up64, up32, dev = lqr.single_env_pair(d, 12.0, verbose=False)
+    assert up64 and up32
+    assert max(dev[:5]) < 5e-5, dev                                                       # 1000 steps: BASELINE's 1e-4 with margin
+    assert max(dev) < 1e-3, dev
