@@ -2566,6 +2566,15 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
   const unsigned hwslot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_ID[3:0]: this wave's slot on its SIMD
 #endif
   for (int s = s_begin; s < s_end; s++) {
+#if !defined(MJB_HOST_EMU) && defined(MJB_LANE_LAUNDER)
+    // Experiment (off; MJB_SPEC_FLAGS=-DMJB_LANE_LAUNDER): the lane index made opaque once per step, so that the lane-derived loop invariants
+    // of the pipeline (`lane < n` predicates, 64-bit table addresses of the baked model) are recomputed where they are used instead of being
+    // hoisted in front of the step loop and spilled there.  VGPR spills 77 -> 43, scratch instructions 132 -> 73, but 2.4 % SLOWER (41.8 vs
+    // 42.8 M env-steps/s): reloading a hoisted value costs less issue than recomputing it.  Bitwise identical either way.
+    MJB_OPAQUE1(lane);
+    __builtin_assume(lane >= 0 && lane < G);
+    c.lane = lane;
+#endif
 #ifndef MJB_HOST_EMU
     // Issue priority of the SIMD's co-resident waves: the hardware arbitrates VALU issue by priority, then AGE, so of two waves that
     // start together the older one runs ~10 % faster for its whole life and the launch waits for the younger (profiles/r02_wave_timeline.log).
