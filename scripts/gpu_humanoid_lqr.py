@@ -217,7 +217,16 @@ def main() -> None:
     dl = dict(d)
     dl["ctrl_std"], dl["perturbations"] = noise_table(model, TUTORIAL, d["bal"], long_s)
     print(f"{args.batch} humanoids, each under its own {args.seconds:.0f} s window of a {long_s:.0f} s noise sequence (env_stride {stride} steps):")
-    balance(dl, min(args.batch, 512), args.seconds, dtype="float64", env_stride=stride)
+    nb = min(args.batch, 512)
+    *_, e64 = balance(dl, nb, args.seconds, dtype="float64", env_stride=stride)
+    *_, e32 = balance(dl, nb, args.seconds, dtype="float32", env_stride=stride)
+    z64, z32 = np.array(e64.data.qpos).reshape(nb, -1)[:, 2], np.array(e32.data.qpos).reshape(nb, -1)[:, 2]
+    s64, s32 = z64 > d["qpos0"][2] - 0.15, z32 > d["qpos0"][2] - 0.15
+    both = s64 & s32
+    dq = np.abs(np.array(e32.data.qpos).reshape(nb, -1) - np.array(e64.data.qpos).reshape(nb, -1)).max(axis=1)
+    print(f"  the same {nb} noise windows in both precisions: standing at the end float64 {int(s64.sum())}, fp32 {int(s32.sum())}, same outcome in {int((s64 == s32).sum())} / {nb}; "
+          f"among the {int(both.sum())} standing in both: fp32 vs float64 |dqpos| median {np.median(dq[both]):.2e}, 90th pct {np.percentile(dq[both], 90):.2e}")
+    del e64, e32
     balance(dl, args.batch, args.seconds, dtype="float32", env_stride=stride)
     print("== the reference's variant (lqr.py:218-238: balance joints = every hip / knee / ankle of BOTH legs, the abdomen among the noisy 'other' joints; default_rng(1), 6 s) ==")
     dr = design(model, CFG)
