@@ -655,3 +655,17 @@ def test_humanoid_balances_on_one_leg_under_the_tutorial_lqr_and_fp32_tracks_flo
     assert up64 and up32
     assert max(dev[:5]) < 5e-5, dev                                                       # 1000 steps: BASELINE's 1e-4 with margin
     assert max(dev) < 1e-3, dev
+    # the closed loop does not depend on how the batch is scheduled: two-wave kernel (512 environments), ticket map (4096), every environment
+    # at its own phase of the noise table -> the first 512 environments are bitwise the same
+    def closed_loop(batch):
+        ctl = mt.LinearFeedbackController(K=d["K"], ctrl0=d["ctrl0"], qpos_goal=d["qpos0"], ctrl_noise_std=d["ctrl_std"],
+                                          perturbations=d["perturbations"], env_stride=3)
+        env = mt.Env.from_xml_path(MODELS["humanoid"], controller=ctl, keyframe=1, batch=batch)
+        env.data.qpos[...] = d["qpos0"]
+        env.data.qvel[...] = 0.0
+        env.rollout(150)
+        return np.array(env.data.qpos), env.data.sim.schedule_info()
+    qa, sa = closed_loop(512)
+    qb, sb = closed_loop(4096)
+    assert sa["waves_per_env"] == 2 and sb["map"] == "tickets"
+    assert np.array_equal(qb[:512], qa) and np.abs(qa - d["qpos0"]).max() > 1e-3
