@@ -530,3 +530,17 @@ def test_oracle_humanoid_keeps_its_one_leg_balance_under_the_tutorial_lqr(oracle
     assert 0.1 < exc < 1.0                                                                     # and it was really pushed around
     c = d.contacts()
     assert set(zip(c["geom1"].tolist(), c["geom2"].tolist())) <= {(0, model.geom("foot1_left").id), (0, model.geom("foot2_left").id)}
+
+
+def test_inverse_dynamics_at_the_one_leg_keyframe_matches_the_tutorials_printout(oracle):
+    """Informational anchor, provenance stated plainly: DeepMind's LQR tutorial prints ``data.qfrc_inverse`` for the ``stand_on_left_leg``
+    keyframe at zero acceleration (the cell the reference keeps as LQR.txt:159-163, WITHOUT its output).  The published output, as this
+    file's author remembers it to four digits - it is not held by the reference, so it pins nothing formally - begins
+    ``[0, 0, 2.759e+02, -3.319e+01, 4.995e+00, -6.688e+00, -4.305e+00, 3.693e+00, ...]``: the 275.9 N on the vertical root dof is the weight
+    (400.7 N) minus what the soft foot contact carries at the keyframe's penetration, the next three are root torques.  The oracle's
+    inverse dynamics with contact reproduces those eight numbers to the printed precision."""
+    m, d = oracle("humanoid")
+    d.reset_keyframe(1); d.forward(); d.qacc[:] = 0; d.inverse()
+    got = np.array(d.qfrc_inverse)[:8]
+    assert got[0] == 0.0 and got[1] == 0.0                                                 # no horizontal force: frictionless-at-rest contact normal is vertical
+    assert ["%.3e" % v for v in got[2:]] == ["2.759e+02", "-3.319e+01", "4.995e+00", "-6.688e+00", "-4.305e+00", "3.693e+00"], got
