@@ -114,6 +114,15 @@ int mjb_host_view(mjbData* d, const char* name, double** host_ptr, long* per_env
 int mjb_sync_to_host(mjbData* d);
 int mjb_sync_to_device(mjbData* d, int field_mask);
 int mjb_step_host(mjbData* d, int nstep, int field_mask);
+/* Edit detection inside the library: the reference's controllers write data.ctrl / qpos / qvel IN PLACE through the numpy views
+ * (control.py:26-32, examples/drone2/main.py:393-397), so "what did the host change since the block was last refreshed" is a comparison
+ * of the pinned block with a library-owned shadow copy.  mjb_mirror_edited_mask: bit k set = field k differs from the shadow;
+ * mjb_mirror_commit: the shadow takes the block's current content for the fields in field_mask (after a refresh or an upload);
+ * mjb_step_host_auto = [compare != 0: edited mask, else 0] + mjb_step_host(nstep, mask) + commit(all): ONE call per reference-style
+ * Env.step; *mask_out (may be NULL) receives the mask that was uploaded. */
+int mjb_mirror_edited_mask(mjbData* d, int* mask_out);
+int mjb_mirror_commit(mjbData* d, int field_mask);
+int mjb_step_host_auto(mjbData* d, int nstep, int compare, int* mask_out);
 
 /* ---- per-model specialisation of the fp32 step kernel (no reference counterpart: the reference's MjModel is interpreted by
  * one pre-built C library; here the structural sizes of the compiled model and the LDS layout offsets can be folded into the

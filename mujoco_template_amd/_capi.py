@@ -128,12 +128,15 @@ def load_library() -> ctypes.CDLL:
     L.mjb_sync_to_host.argtypes = [vp]
     L.mjb_sync_to_device.argtypes = [vp, ci]
     L.mjb_step_host.argtypes = [vp, ci, ci]
+    L.mjb_mirror_edited_mask.argtypes = [vp, ctypes.POINTER(ci)]
+    L.mjb_mirror_commit.argtypes = [vp, ci]
+    L.mjb_step_host_auto.argtypes = [vp, ci, ci, ctypes.POINTER(ci)]
     for name in ("mjb_model_create", "mjb_model_set_disableactuator", "mjb_model_set_solver", "mjb_data_create", "mjb_set_stream",
                  "mjb_sync", "mjb_data_info", "mjb_array_ptr", "mjb_get_array", "mjb_set_array", "mjb_get_counters", "mjb_reset",
                  "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_fd_spec_load", "mjb_fd_spec_unload", "mjb_step2_spec_load", "mjb_step2_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get", "mjb_model_field", "mjb_model_field_at", "mjb_model_save",
                  "mjb_model_load", "mjb_model_load_xml", "mjb_model_load_xml_string", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
-                 "mjb_step_host"):
+                 "mjb_step_host", "mjb_mirror_edited_mask", "mjb_mirror_commit", "mjb_step_host_auto"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
@@ -578,6 +581,21 @@ class BatchSim:
 
     def sync_to_device(self, field_mask: int) -> None:
         _check(load_library().mjb_sync_to_device(self.ptr, int(field_mask)))
+
+    def mirror_edited_mask(self) -> int:
+        """Fields of the pinned mirror block the host edited in place since the library last refreshed / uploaded them (bit order of MIRROR_FIELDS)."""
+        out = ctypes.c_int(0)
+        _check(load_library().mjb_mirror_edited_mask(self.ptr, ctypes.byref(out)))
+        return out.value
+
+    def mirror_commit(self, field_mask: int = 63) -> None:
+        _check(load_library().mjb_mirror_commit(self.ptr, int(field_mask)))
+
+    def step_host_auto(self, nstep: int, compare: bool = True) -> int:
+        """Edit detection + ``step_host`` + shadow refresh in ONE library call; returns the mask that was uploaded."""
+        out = ctypes.c_int(0)
+        _check(load_library().mjb_step_host_auto(self.ptr, int(nstep), 1 if compare else 0, ctypes.byref(out)))
+        return out.value
 
     def step_host(self, nstep: int, field_mask: int = 0) -> None:
         """upload the edited mirror fields, ``nstep`` x mj_step (0: mj_forward), refresh the mirror — one library call."""

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -117,6 +118,8 @@ struct mjbData {
   // host mirror (mjb_host_view): ONE pinned float64 block  qpos | qvel | ctrl | qacc | qacc_warmstart | time , each [batch, n],
   // and its device staging twin; filled by one pack kernel + one D2H per mjb_sync_to_host
   double *mirror_host = nullptr, *mirror_dev = nullptr;
+  double* mirror_shadow = nullptr;        // host copy of the block as last refreshed / uploaded: what in-place edits are detected against
+  unsigned long long mirror_seq = 0;      // sequence number of the last polled host-driven step (completion words behind the flags word)
   size_t mirror_off[7] = {0, 0, 0, 0, 0, 0, 0};             // element offsets of the six fields, [6] = total
 };
 
@@ -639,6 +642,7 @@ void mjb_data_free(mjbData* d) {
   (void)hipSetDevice(d->device);
   for (void* p : d->owned) (void)hipFree(p);
   if (d->mirror_host) (void)hipHostFree(d->mirror_host);
+  std::free(d->mirror_shadow);
   if (d->fd_A_host) (void)hipHostFree(d->fd_A_host);
   if (d->fd_B_host) (void)hipHostFree(d->fd_B_host);
   d->alloc.release();
@@ -1267,8 +1271,10 @@ static int ensure_mirror(mjbData* d) {
   for (int k = 0; k < 6; k++) { d->mirror_off[k] = o; o += B * n[k]; }
   d->mirror_off[6] = o;
   HIPCHK(hipSetDevice(d->device));
-  HIPCHK(hipHostMalloc((void**)&d->mirror_host, (o + 1) * sizeof(double), hipHostMallocDefault));   // + the engine-flags word
-  std::memset(d->mirror_host, 0, (o + 1) * sizeof(double));
+  // + the engine-flags word + one completion word per environment (polled by mjb_step_host on the zero-copy path: coherent memory, the
+  // device's stores must be visible to the host while the kernel is still running)
+  HIPCHK(hipHostMalloc((void**)&d->mirror_host, (o + 1 + B) * sizeof(double), hipHostMallocCoherent));
+  std::memset(d->mirror_host, 0, (o + 1 + B) * sizeof(double));
   if (dev_alloc(d, &d->mirror_dev, o + 1)) return fail(MJB_ERR_DEVICE, "device allocation of the mirror staging block failed");
   return MJB_OK;
 }
@@ -1352,8 +1358,26 @@ int mjb_step_host(mjbData* d, int nstep, int field_mask) {
     StepArgs a = make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0);
     a.mirror = d->mirror_host; a.mirror_mask = field_mask & 63;
     double* flagword = d->mirror_host + d->mirror_off[6];
+    // short launches: poll the environments' completion words in the pinned block instead of waiting for the end-of-kernel signal
+    // (the state words are published before them; whatever else the kernel's epilogue writes is ordered by the stream for later calls)
+    static const bool poll_ok = !(std::getenv("MJB_HOST_POLL") && std::atoi(std::getenv("MJB_HOST_POLL")) == 0);
+    const bool poll = poll_ok && nstep <= 64;
+    if (poll) a.mirror_seq = ++d->mirror_seq;
     if ((rc = launch(d, a, none, nullptr, false)) != MJB_OK) return rc;
-    HIPCHK(hipStreamSynchronize(d->stream));
+    bool done = false;
+    if (poll) {
+      const unsigned long long* words = (const unsigned long long*)(flagword + 1);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned long spins = 0;; spins++) {
+        int e = 0;
+        while (e < d->batch && __atomic_load_n(words + e, __ATOMIC_ACQUIRE) == a.mirror_seq) e++;
+        if (e == d->batch) { done = true; break; }
+        __builtin_ia32_pause();
+        // a launch that has not finished after 20 ms is not the short step this path is for (or has faulted): let the runtime wait and report
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+      }
+    }
+    if (!done) HIPCHK(hipStreamSynchronize(d->stream));
     if (*flagword < 0) {                                       // some environment raised an engine flag: fetch the sticky word
       int fl = 0;
       HIPCHK(hipMemcpy(&fl, d->df.flags, sizeof(int), hipMemcpyDeviceToHost));
@@ -1365,6 +1389,50 @@ int mjb_step_host(mjbData* d, int nstep, int field_mask) {
   if (nstep > 0 && (rc = launch(d, make_args(d, nstep, MJB_CTRL_KEEP, 0, 0, 1.0, 0), none, nullptr, false)) != MJB_OK) return rc;
   if (nstep == 0 && (rc = launch(d, make_args(d, 1, MJB_CTRL_KEEP, 0, 0, 1.0, 1), none, nullptr, false)) != MJB_OK) return rc;   // mj_forward
   return mirror_pull(d);
+}
+
+static int ensure_shadow(mjbData* d) {
+  int rc = ensure_mirror(d);
+  if (rc != MJB_OK) return rc;
+  if (!d->mirror_shadow) {
+    d->mirror_shadow = (double*)std::malloc(d->mirror_off[6] * sizeof(double));
+    if (!d->mirror_shadow) return fail(MJB_ERR_ARG, "out of host memory for the mirror shadow");
+    std::memcpy(d->mirror_shadow, d->mirror_host, d->mirror_off[6] * sizeof(double));
+  }
+  return MJB_OK;
+}
+
+int mjb_mirror_edited_mask(mjbData* d, int* mask_out) {
+  if (!d || !mask_out) return fail(MJB_ERR_ARG, "NULL argument");
+  int rc = ensure_shadow(d);
+  if (rc != MJB_OK) return rc;
+  int mask = 0;
+  for (int k = 0; k < 6; k++) {
+    const size_t a = d->mirror_off[k], b = d->mirror_off[k + 1];
+    if (b > a && std::memcmp(d->mirror_host + a, d->mirror_shadow + a, (b - a) * sizeof(double)) != 0) mask |= 1 << k;   // bitwise: -0.0 / NaN payload edits count
+  }
+  *mask_out = mask;
+  return MJB_OK;
+}
+
+int mjb_mirror_commit(mjbData* d, int field_mask) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  int rc = ensure_shadow(d);
+  if (rc != MJB_OK) return rc;
+  for (int k = 0; k < 6; k++) if ((field_mask >> k) & 1) {
+    const size_t a = d->mirror_off[k], b = d->mirror_off[k + 1];
+    std::memcpy(d->mirror_shadow + a, d->mirror_host + a, (b - a) * sizeof(double));
+  }
+  return MJB_OK;
+}
+
+int mjb_step_host_auto(mjbData* d, int nstep, int compare, int* mask_out) {
+  if (!d) return fail(MJB_ERR_ARG, "data is NULL");
+  int mask = 0, rc;
+  if (compare && (rc = mjb_mirror_edited_mask(d, &mask)) != MJB_OK) return rc;
+  if (mask_out) *mask_out = mask;
+  if ((rc = mjb_step_host(d, nstep, mask)) != MJB_OK) return rc;
+  return mjb_mirror_commit(d, 63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -2470,7 +2470,7 @@ MJB_DEV void mirror_in(MRef m, LayRef L, T* w, const double* mir, int mask, int 
   if (mask & 32) time = *mt;
 }
 template <typename T, int G, typename MRef>
-MJB_DEV void mirror_out(MRef m, LayRef L, const T* w, double* mir, int env, int batch, int lane, double time, int fl) {
+MJB_DEV void mirror_out(MRef m, LayRef L, const T* w, double* mir, int env, int batch, int lane, double time, int fl, unsigned long long seq = 0) {
   const size_t B = (size_t)batch, nq = m.nq, nv = m.nv, nu = m.nu;
   double *mq = mir + (size_t)env * nq, *mv = mir + B * nq + (size_t)env * nv, *mc = mir + B * (nq + nv) + (size_t)env * nu;
   double *ma = mir + B * (nq + nv + nu) + (size_t)env * nv, *mw = ma + B * nv, *mt = mir + B * (nq + 3 * nv + nu) + env;
@@ -2481,6 +2481,14 @@ MJB_DEV void mirror_out(MRef m, LayRef L, const T* w, double* mir, int env, int 
     *mt = time;
     if (fl) mir[B * (nq + 3 * nv + nu + 1)] = -1.0;           // "engine flags changed": the host fetches the sticky word (no read-modify-write over the bus)
   }
+#ifndef MJB_HOST_EMU
+  if (seq != 0) {
+    // completion word of this environment (behind the flags word): every lane's state stores above are complete at system scope once
+    // the wave has passed the fence; then ONE release store publishes them to the polling host
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store((unsigned long long*)(mir + B * (nq + 3 * nv + nu + 1) + 1) + env, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#endif
 }
 
 // Hand-over of an environment between the chunks of ONE launch (ticket mode of k_step, mjb_kernels.hpp): the wave that ends chunk
@@ -2670,7 +2678,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
   }
 #ifndef MJB_HOST_EMU
-  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0));
+  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0), a.mirror_seq);
 #endif
   if (a.write_kin) {
     for (int i = lane; i < 3 * m.nbody; i += G) {
@@ -2812,7 +2820,7 @@ MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, 
     d.time[env] = time;
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
   }
-  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (mail[2] ? 1 : 0) | (mail[3] ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0));
+  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (mail[2] ? 1 : 0) | (mail[3] ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0), a.mirror_seq);
   for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
   for (int i = lane; i < nv; i += G) {
     d.qvel[(size_t)env * nv + i] = (TS)w[L.qvel + i];

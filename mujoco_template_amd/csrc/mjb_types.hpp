@@ -151,6 +151,9 @@ struct StepArgs {
   // back at the end - no staging copies, no pack / unpack kernels.  nullptr otherwise.
   double* mirror;
   int mirror_mask;
+  // != 0: after its state words an environment stores this sequence number into its completion word of the mirror block (system-scope
+  // release, behind a system-scope fence): the host polls those words instead of waiting for the end-of-kernel signal (mjb_step_host)
+  unsigned long long mirror_seq;
   int fair_bit;          // >0: alternate the issue priority of a SIMD's waves by this bit of the 100 MHz clock (env_run); 0 = leave the hardware's age order
   unsigned ticket_base;  // ticket mode: value of d.sched[0] when this launch starts (the counter is not reset between launches)
   unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ the step index at which the hand-over happens), unique among the launches that could still be in the buffer

@@ -227,7 +227,6 @@ class MjData:
         # state mirrors = numpy views over the library's pinned float64 block (mjb_host_view): ONE packed copy per direction
         self._mirror: dict[str, np.ndarray] = {name: self._sim.host_view(name) for name in MIRROR_FIELDS}
         self._flags = self._sim.host_view("engine_flags")          # one sticky word, refreshed by the same packed copy
-        self._shadow: dict[str, np.ndarray] = {}
         self._state_stale = True                                   # the device state is newer than the mirror block
         self._dev_newer: set[str] = set(_DERIVED)                  # derived arrays are pulled one by one, on demand
         self.act = np.zeros(0) if self.batch == 1 else np.zeros((self.batch, 0))
@@ -250,13 +249,8 @@ class MjData:
         return self._sim
 
     def _refresh_shadow(self) -> None:
-        # preallocated shadows, filled in place: no 4 MB of fresh arrays per host-driven step at batch 4096
-        for name in MIRROR_FIELDS:
-            sh = self._shadow.get(name)
-            if sh is None or sh.shape != self._mirror[name].shape:
-                self._shadow[name] = self._mirror[name].copy()
-            else:
-                np.copyto(sh, self._mirror[name])
+        # the shadow copy the in-place edits are detected against lives in the library (mjb_mirror_commit: one memcpy per field)
+        self._sim.mirror_commit(63)
         self._state_stale = False
 
     def _pull(self, name: str) -> None:
@@ -274,25 +268,20 @@ class MjData:
         """Bit mask (order of ``MIRROR_FIELDS``) of the mirrors the user edited in place since they were last refreshed."""
         if self._state_stale:
             return 0                                               # nothing pulled since the last launch: nothing to compare against
-        mask = 0
-        for bit, name in enumerate(MIRROR_FIELDS):
-            if not np.array_equal(self._mirror[name], self._shadow[name]):
-                mask |= 1 << bit
-        return mask
+        return self._sim.mirror_edited_mask()                      # bitwise comparison with the library's shadow copy (C, no temporaries)
 
     def push_host_edits(self) -> None:
         """Upload mirrors the user edited in place since they were last pulled (one packed copy)."""
         mask = self._edited_mask()
         if mask:
             self._sim.sync_to_device(mask)
-            for bit, name in enumerate(MIRROR_FIELDS):
-                if (mask >> bit) & 1:
-                    np.copyto(self._shadow[name], self._mirror[name])
+            self._sim.mirror_commit(mask)
 
     def step_host(self, nstep: int) -> None:
-        """Host-driven step: edited fields up, ``nstep`` x mj_step (0 = mj_forward), whole state block back — one library call."""
-        self._sim.step_host(int(nstep), self._edited_mask())
-        self._refresh_shadow()
+        """Host-driven step: edited fields up, ``nstep`` x mj_step (0 = mj_forward), whole state block back — ONE library call
+        (edit detection and the shadow refresh included: ``mjb_step_host_auto``)."""
+        self._sim.step_host_auto(int(nstep), compare=not self._state_stale)
+        self._state_stale = False
         self._dev_newer = set(_DERIVED)
         self._check_engine_counters()
 

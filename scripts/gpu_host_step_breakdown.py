@@ -33,4 +33,4 @@ dt = (time.perf_counter() - t) / N
 print(f"   BatchSim.step_host(1, ctrl) alone: {dt*1e6:.1f} us")
 t = time.perf_counter()
 for _ in range(N): d._edited_mask()
-print(f"   edit detection (numpy compares of the six mirrors): {(time.perf_counter()-t)/N*1e6:.1f} us")
+print(f"   edit detection (mjb_mirror_edited_mask: memcmp of the six fields with the library's shadow): {(time.perf_counter()-t)/N*1e6:.1f} us")
