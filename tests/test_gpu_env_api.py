@@ -450,6 +450,28 @@ def test_host_mirror_is_one_pinned_block_and_steps_match_the_device_path():
     assert d.time == pytest.approx(0.5 + h.model.opt.timestep)
     assert d.sim.get("time")[:, 0] == pytest.approx(0.5 + h.model.opt.timestep)
     assert d.engine_warnings == []
+    # edit detection lives in the library (mjb_mirror_edited_mask / mjb_mirror_commit / mjb_step_host_auto): bitwise comparison of the
+    # pinned block with its shadow, per field, bit order of MIRROR_FIELDS
+    sim = d.sim
+    assert sim.mirror_edited_mask() == 0
+    d.ctrl[2, 3] += 0.125
+    assert sim.mirror_edited_mask() == 4
+    d.qpos[0, 2] += 1e-9
+    d.qacc_warmstart[1, 0] = 7.0
+    assert sim.mirror_edited_mask() == 1 | 4 | 16
+    sim.mirror_commit(1)
+    assert sim.mirror_edited_mask() == 4 | 16
+    assert sim.step_host_auto(1) == 4 | 16 and sim.mirror_edited_mask() == 0             # uploaded what differed, shadow refreshed
+    assert sim.get("ctrl")[2, 3] == np.float32(d.ctrl[2, 3])
+    assert sim.step_host_auto(0, compare=False) == 0                                       # mj_forward, nothing compared
+    # the small-batch path returns on the environments' completion words (polled), the large one on the stream: same results
+    big = mt.ModelHandle.from_xml_path(MODELS["humanoid"], batch=80, dtype="float32")      # block > 64 KB: staged copies, no polling
+    big.data.ctrl[:] = np.tile(u, (14, 1))[:80]
+    d.ctrl[:] = u
+    d.qpos[:] = big.data.qpos[:B]; d.qvel[:] = big.data.qvel[:B]; d.qacc_warmstart[:] = big.data.qacc_warmstart[:B]; d.qacc[:] = big.data.qacc[:B]; d.time = 0.0; big.data.time = 0.0
+    for _ in range(3):
+        h.step(); big.step()
+    assert np.array_equal(d.qpos, big.data.qpos[:B]) and np.array_equal(d.qvel, big.data.qvel[:B])
 
 
 def test_truncated_physics_is_surfaced_once():
