@@ -691,3 +691,34 @@ def test_humanoid_balances_on_one_leg_under_the_tutorial_lqr_and_fp32_tracks_flo
     qb, sb = closed_loop(4096)
     assert sa["waves_per_env"] == 2 and sb["map"] == "tickets"
     assert np.array_equal(qb[:512], qa) and np.abs(qa - d["qpos0"]).max() > 1e-3
+
+
+def test_cartpole_config2_batch_1024_recovers_under_the_references_pid_as_a_device_law(oracle):
+    """The reference's cart-pole example on the engine at BASELINE config[1]'s batch: its PID law with the shipped gains
+    (examples/cartpole/controllers/pid.py:26-49, cartpole_config.py:72-79; ki = 0, so it IS a linear state feedback) as a
+    LinearFeedbackController inside the fused kernel, 1024 initial pole angles across +-30 degrees (the example starts at 30).  Every
+    environment settles at the origin in fp32 and float64; the 30-degree one follows the oracle driven by the same law from Python."""
+    B = 1024
+    K = -np.array([[1.11, 16.66, 2.20, 4.45]])                      # ctrl = u0 - K [q - q0; v]  ->  + kp_x x + kp_th th + kd_x xd + kd_th thd
+    ang = np.deg2rad(np.linspace(-30.0, 30.0, B))
+    out = {}
+    for dtype in ("float64", "float32"):
+        ctl = mt.LinearFeedbackController(K=K, ctrl0=np.zeros(1), qpos_goal=np.zeros(2))
+        env = mt.Env.from_xml_path(MODELS["cartpole"], controller=ctl, batch=B, dtype=dtype)
+        env.data.qpos[:, 0] = 0.0
+        env.data.qpos[:, 1] = ang
+        env.data.qvel[...] = 0.0
+        env.rollout(300)
+        mid = np.array(env.data.qpos)
+        env.rollout(900)
+        q, v = np.array(env.data.qpos), np.array(env.data.qvel)
+        assert np.abs(q).max() < 2e-3 and np.abs(v).max() < 2e-3, dtype
+        out[dtype] = mid
+    m, d = oracle("cartpole")
+    d.reset(); d.qpos[:] = [0.0, ang[-1]]; d.qvel[:] = 0
+    for s in range(300):
+        d.ctrl[0] = np.clip(1.11 * d.qpos[0] + 2.20 * d.qvel[0] + 16.66 * d.qpos[1] + 4.45 * d.qvel[1], -200.0, 200.0)
+        d.step()
+    assert np.abs(out["float64"][-1] - d.qpos).max() < 1e-9
+    assert np.abs(out["float32"][-1] - d.qpos).max() < 1e-4          # closed loop, 300 steps: BASELINE's drift bound
+    assert np.abs(out["float32"] - out["float64"]).max() < 1e-4

@@ -544,3 +544,26 @@ def test_inverse_dynamics_at_the_one_leg_keyframe_matches_the_tutorials_printout
     got = np.array(d.qfrc_inverse)[:8]
     assert got[0] == 0.0 and got[1] == 0.0                                                 # no horizontal force: frictionless-at-rest contact normal is vertical
     assert ["%.3e" % v for v in got[2:]] == ["2.759e+02", "-3.319e+01", "4.995e+00", "-6.688e+00", "-4.305e+00", "3.693e+00"], got
+
+
+def test_cartpole_recovers_under_the_references_pid_gains(oracle):
+    """Behavioural anchor with reference-held numbers: the cart-pole example's PID gains (examples/cartpole/cartpole_config.py:72-79, tuned by
+    its authors against real MuJoCo; law examples/cartpole/controllers/pid.py:26-49, ki = 0) and its initial state (pole at 30 degrees,
+    cartpole_config.py:64-69).  On the oracle the same law catches the pole, keeps the cart inside the slider's +-2 m and settles at the
+    origin - the signs of the hinge axis, the slide axis and the gear, and the magnitudes of M and the bias force all enter."""
+    m, d = oracle("cartpole")
+    d.reset(); d.qpos[:] = [0.0, np.deg2rad(30.0)]; d.qvel[:] = 0
+    xmax = 0.0
+    for s in range(1200):
+        u = 1.11 * d.qpos[0] + 2.20 * d.qvel[0] + 16.66 * d.qpos[1] + 4.45 * d.qvel[1]
+        d.ctrl[0] = np.clip(u, -200.0, 200.0)
+        d.step()
+        xmax = max(xmax, abs(float(d.qpos[0])))
+        assert abs(d.qpos[1]) < np.deg2rad(31.0)
+    assert 1.0 < xmax < 1.9                                   # a real excursion, inside the slider range (no limit row ever active)
+    assert abs(d.qpos[0]) < 1e-3 and abs(d.qpos[1]) < 1e-4 and np.abs(d.qvel).max() < 1e-3
+    d.reset(); d.qpos[:] = [0.0, np.deg2rad(30.0)]; d.qvel[:] = 0
+    for s in range(300):                                      # the same gains with the opposite sign on the angle: the pole goes over
+        d.ctrl[0] = np.clip(1.11 * d.qpos[0] + 2.20 * d.qvel[0] - 16.66 * d.qpos[1] - 4.45 * d.qvel[1], -200.0, 200.0)
+        d.step()
+    assert abs(d.qpos[1]) > np.deg2rad(60.0)
