@@ -1380,6 +1380,7 @@ int mjb_step_host(mjbData* d, int nstep, int field_mask) {
     if (!done) HIPCHK(hipStreamSynchronize(d->stream));
     if (*flagword < 0) {                                       // some environment raised an engine flag: fetch the sticky word
       int fl = 0;
+      if (done) HIPCHK(hipStreamSynchronize(d->stream));        // (rare) the polled return left the kernel's epilogue in flight: the copy below must not overtake it
       HIPCHK(hipMemcpy(&fl, d->df.flags, sizeof(int), hipMemcpyDeviceToHost));
       *flagword = (double)fl;
     }
