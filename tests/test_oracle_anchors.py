@@ -567,3 +567,45 @@ def test_cartpole_recovers_under_the_references_pid_gains(oracle):
         d.ctrl[0] = np.clip(1.11 * d.qpos[0] + 2.20 * d.qvel[0] - 16.66 * d.qpos[1] - 4.45 * d.qvel[1], -200.0, 200.0)
         d.step()
     assert abs(d.qpos[1]) > np.deg2rad(60.0)
+
+
+def test_contact_geometry_of_the_non_plane_primitive_pairs():
+    """Hand-derived closest-point geometry for the pairs the humanoid's self-collisions use (capsule-capsule skew and end-cap cases,
+    sphere-capsule, sphere-sphere); MuJoCo's convention: dist = centre-line distance - r1 - r2, normal from geom1 to geom2,
+    pos midway between the two surfaces.  Each pair sits 10 m from the others; contype / conaffinity pick the pairs.
+
+    A  capsule x-axis at (0,0,0), half-length 0.5, r 0.1      B  capsule y-axis at (0.2, 0.1, 0.15), half-length 0.5, r 0.1
+       closest points (0.2,0,0) / (0.2,0,0.15): dist 0.15 - 0.2 = -0.05, normal +z, pos z = 0.1 - 0.025
+    C  capsule x-axis at (10,0,0), half-length 0.5, r 0.1     D  capsule y-axis at (10.6, 0, 0.08), half-length 0.5, r 0.05
+       beyond the end of C: end point (10.5,0,0) / (10.6,0,0.08): v = (0.1,0,0.08), d = |v| = 0.12806, dist = d - 0.15, normal v / d
+    E  capsule x-axis at (20,0,0), half-length 0.5, r 0.1     F  sphere r 0.1 at (20.3, 0, 0.17): dist -0.03, normal +z, pos z = 0.085
+    G  sphere r 0.1 at (30,0,0)                               H  sphere r 0.2 at (30.15, 0.2, 0): d 0.25, dist -0.05, normal (0.6, 0.8, 0)"""
+    rot_y = 'quat="0.7071067811865476 0 0.7071067811865476 0"'       # capsule axis z -> x
+    rot_x = 'quat="0.7071067811865476 -0.7071067811865476 0 0"'      # capsule axis z -> y
+    xml = f"""<mujoco><option gravity="0 0 0"/><worldbody>
+      <body pos="0 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_y} contype="1" conaffinity="1"/></body>
+      <body pos="0.2 0.1 0.15"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_x} contype="1" conaffinity="1"/></body>
+      <body pos="10 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_y} contype="2" conaffinity="2"/></body>
+      <body pos="10.6 0 0.08"><freejoint/><geom type="capsule" size="0.05 0.5" {rot_x} contype="2" conaffinity="2"/></body>
+      <body pos="20 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_y} contype="4" conaffinity="4"/></body>
+      <body pos="20.3 0 0.17"><freejoint/><geom type="sphere" size="0.1" contype="4" conaffinity="4"/></body>
+      <body pos="30 0 0"><freejoint/><geom type="sphere" size="0.1" contype="8" conaffinity="8"/></body>
+      <body pos="30.15 0.2 0"><freejoint/><geom type="sphere" size="0.2" contype="8" conaffinity="8"/></body>
+      </worldbody></mujoco>"""
+    cm = mjcf.compile_xml_string(xml)
+    d = mjo.OracleData(mjo.OracleModel(cm))
+    d.forward()
+    con = d.contacts()
+    assert d.counters()["ncon"] == 4
+    order = np.argsort(con["pos"][:, 0])
+    dist, pos, nrm = con["dist"][order], con["pos"][order], con["frame"][order][:, 0, :]
+    g1, g2 = con["geom1"][order], con["geom2"][order]
+    for k in range(4):                                               # normals reported from geom1 to geom2 whatever the pair order
+        if g1[k] > g2[k]:
+            nrm[k] = -nrm[k]
+    v = np.array([0.1, 0.0, 0.08])
+    dv = float(np.linalg.norm(v))
+    assert dist == pytest.approx([-0.05, dv - 0.15, -0.03, -0.05], abs=1e-12)
+    assert nrm == pytest.approx(np.array([[0, 0, 1], v / dv, [0, 0, 1], [0.6, 0.8, 0]]), abs=1e-12)
+    e = np.array([10.5, 0, 0]) + v / dv * (0.1 + 0.5 * (dv - 0.15))
+    assert pos == pytest.approx(np.array([[0.2, 0, 0.075], e, [20.3, 0, 0.085], [30 + 0.6 * 0.075, 0.8 * 0.075, 0]]), abs=1e-12)
