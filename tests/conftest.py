@@ -88,3 +88,17 @@ def oracle(compiled):
         return cache[name], mjo.OracleData(cache[name])
 
     return get
+
+# four non-plane primitive pairs, 10 m apart (hand-derived contact geometry in tests/test_oracle_anchors.py)
+_ROT_Y = 'quat="0.7071067811865476 0 0.7071067811865476 0"'       # capsule axis z -> x
+_ROT_X = 'quat="0.7071067811865476 -0.7071067811865476 0 0"'      # capsule axis z -> y
+PAIRS_XML = f"""<mujoco><option gravity="0 0 0"/><worldbody>
+  <body pos="0 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {_ROT_Y} contype="1" conaffinity="1"/></body>
+  <body pos="0.2 0.1 0.15"><freejoint/><geom type="capsule" size="0.1 0.5" {_ROT_X} contype="1" conaffinity="1"/></body>
+  <body pos="10 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {_ROT_Y} contype="2" conaffinity="2"/></body>
+  <body pos="10.6 0 0.08"><freejoint/><geom type="capsule" size="0.05 0.5" {_ROT_X} contype="2" conaffinity="2"/></body>
+  <body pos="20 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {_ROT_Y} contype="4" conaffinity="4"/></body>
+  <body pos="20.3 0 0.17"><freejoint/><geom type="sphere" size="0.1" contype="4" conaffinity="4"/></body>
+  <body pos="30 0 0"><freejoint/><geom type="sphere" size="0.1" contype="8" conaffinity="8"/></body>
+  <body pos="30.15 0.2 0"><freejoint/><geom type="sphere" size="0.2" contype="8" conaffinity="8"/></body>
+  </worldbody></mujoco>"""

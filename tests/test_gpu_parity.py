@@ -115,6 +115,35 @@ def test_parallel_capsules_two_contacts(dtype):
     assert np.abs(sim.get("qpos")[0] - od.qpos).max() <= (1e-10 if dtype == "float64" else 2e-6)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_non_plane_primitive_pairs_match_the_hand_derived_geometry(dtype):
+    """Skew capsules, capsule end cap against a capsule, sphere-capsule, sphere-sphere (tests/conftest.py PAIRS_XML; the numbers are
+    derived by hand in tests/test_oracle_anchors.py): contact distance, position and normal of the kernels against the oracle AND
+    against the hand-derived values, then a few steps of the resulting push-apart dynamics."""
+    from tests.conftest import PAIRS_XML
+
+    cm = mjcf.compile_xml_string(PAIRS_XML)
+    om, dm = mjo.OracleModel(cm), DeviceModel(cm)
+    od = mjo.OracleData(om)
+    od.forward()
+    sim = BatchSim(dm, 2, dtype=dtype)
+    sim.debug_forward()
+    assert sim.counters()["ncon"].tolist() == [4, 4]
+    con = sim.debug_get("con").reshape(2, sim.nconmax, 11)[1, :4]
+    ref = od.contacts()
+    tol = 1e-12 if dtype == "float64" else 3e-6                     # fp32: positions up to 30 m from the origin
+    assert np.abs(con[:, 0] - ref["dist"]).max() <= tol and np.abs(con[:, 1:4] - ref["pos"]).max() <= tol
+    assert np.abs(con[:, 4:7] - ref["frame"][:, 0, :]).max() <= (1e-12 if dtype == "float64" else 1e-5)
+    dv = float(np.hypot(0.1, 0.08))
+    assert sorted(con[:, 0].tolist()) == pytest.approx(sorted([-0.05, dv - 0.15, -0.03, -0.05]), abs=tol)     # the hand-derived anchor
+    nstep = 10
+    sim.step(nstep)
+    for _ in range(nstep):
+        od.step()
+    assert np.abs(sim.get("qpos")[1] - od.qpos).max() <= (1e-10 if dtype == "float64" else 5e-6)
+    assert np.abs(od.qvel).max() > 1e-3                              # the contacts really pushed
+
+
 def test_sliding_box_four_corner_contacts_with_friction():
     """plane-box contacts (4 corners x 4 pyramid rows) under sliding friction: a box thrown along the floor at 2 m/s with some spin.
     float64 kernels follow the oracle through the stick-slip hopping (tests/test_oracle_anchors.py::test_coulomb_friction...) to

@@ -580,18 +580,8 @@ def test_contact_geometry_of_the_non_plane_primitive_pairs():
        beyond the end of C: end point (10.5,0,0) / (10.6,0,0.08): v = (0.1,0,0.08), d = |v| = 0.12806, dist = d - 0.15, normal v / d
     E  capsule x-axis at (20,0,0), half-length 0.5, r 0.1     F  sphere r 0.1 at (20.3, 0, 0.17): dist -0.03, normal +z, pos z = 0.085
     G  sphere r 0.1 at (30,0,0)                               H  sphere r 0.2 at (30.15, 0.2, 0): d 0.25, dist -0.05, normal (0.6, 0.8, 0)"""
-    rot_y = 'quat="0.7071067811865476 0 0.7071067811865476 0"'       # capsule axis z -> x
-    rot_x = 'quat="0.7071067811865476 -0.7071067811865476 0 0"'      # capsule axis z -> y
-    xml = f"""<mujoco><option gravity="0 0 0"/><worldbody>
-      <body pos="0 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_y} contype="1" conaffinity="1"/></body>
-      <body pos="0.2 0.1 0.15"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_x} contype="1" conaffinity="1"/></body>
-      <body pos="10 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_y} contype="2" conaffinity="2"/></body>
-      <body pos="10.6 0 0.08"><freejoint/><geom type="capsule" size="0.05 0.5" {rot_x} contype="2" conaffinity="2"/></body>
-      <body pos="20 0 0"><freejoint/><geom type="capsule" size="0.1 0.5" {rot_y} contype="4" conaffinity="4"/></body>
-      <body pos="20.3 0 0.17"><freejoint/><geom type="sphere" size="0.1" contype="4" conaffinity="4"/></body>
-      <body pos="30 0 0"><freejoint/><geom type="sphere" size="0.1" contype="8" conaffinity="8"/></body>
-      <body pos="30.15 0.2 0"><freejoint/><geom type="sphere" size="0.2" contype="8" conaffinity="8"/></body>
-      </worldbody></mujoco>"""
+    from tests.conftest import PAIRS_XML as xml
+
     cm = mjcf.compile_xml_string(xml)
     d = mjo.OracleData(mjo.OracleModel(cm))
     d.forward()
