@@ -599,3 +599,36 @@ def test_contact_geometry_of_the_non_plane_primitive_pairs():
     assert nrm == pytest.approx(np.array([[0, 0, 1], v / dv, [0, 0, 1], [0.6, 0.8, 0]]), abs=1e-12)
     e = np.array([10.5, 0, 0]) + v / dv * (0.1 + 0.5 * (dv - 0.15))
     assert pos == pytest.approx(np.array([[0.2, 0, 0.075], e, [20.3, 0, 0.085], [30 + 0.6 * 0.075, 0.8 * 0.075, 0]]), abs=1e-12)
+
+
+def test_inertia_box_fluid_forces_on_the_falling_drone(oracle):
+    """The drone model carries air (x2.xml:4: density 1.225, viscosity 1.8e-5) -> MuJoCo's inertia-box fluid model acts on its one body.
+    Expected passive force recomputed here from the model's mass / principal inertia with the published formulas (equivalent box side
+    b_i = sqrt(6 (I_j + I_k - I_i) / m); Stokes terms -3 pi d beta v and -pi d^3 beta w with d the mean side; quadratic terms
+    -1/2 rho b_j b_k |v_i| v_i and -rho b_i (b_j^4 + b_k^4) |w_i| w_i / 64, all per axis of the body's inertial frame), then mapped to
+    the free joint's dofs: world-frame force, body-frame torque about the joint origin."""
+    m, d = oracle("drone2")
+    cm = m.compiled
+    mass, I = float(cm.body_mass[1]), np.array(cm.body_inertia[1], dtype=float)
+    ipos, iq = np.array(cm.body_ipos[1], dtype=float), np.array(cm.body_iquat[1], dtype=float)
+    w, x, y, z = iq
+    Ri = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])      # inertial frame -> body frame
+    b = np.sqrt(6.0 * np.array([I[1] + I[2] - I[0], I[0] + I[2] - I[1], I[0] + I[1] - I[2]]) / mass)
+    rho, beta = 1.225, 1.8e-5
+    assert cm.density == rho and cm.viscosity == beta
+    dm = b.mean()
+    d.reset(); d.qpos[2] += 50.0
+    v_world, w_body = np.array([1.5, -0.7, -6.0]), np.array([0.8, -1.1, 2.0])
+    d.qvel[:3], d.qvel[3:6] = v_world, w_body                       # identity orientation: body frame = world frame
+    d.forward()
+    assert d.counters()["ncon"] == 0
+    vc = v_world + np.cross(w_body, ipos)                           # velocity of the inertial-frame origin (the com)
+    lv, lw = Ri.T @ vc, Ri.T @ w_body                               # ... in inertial-frame axes
+    f = -3 * np.pi * dm * beta * lv - 0.5 * rho * np.array([b[1] * b[2], b[0] * b[2], b[0] * b[1]]) * np.abs(lv) * lv
+    t = -np.pi * dm ** 3 * beta * lw - rho * b * np.array([b[1] ** 4 + b[2] ** 4, b[0] ** 4 + b[2] ** 4, b[0] ** 4 + b[1] ** 4]) * np.abs(lw) * lw / 64.0
+    F, T = Ri @ f, Ri @ t + np.cross(ipos, Ri @ f)                  # at the joint origin, body (= world) axes
+    assert np.abs(F).max() > 0.01                                   # a real force (tens of millinewtons to newtons)
+    assert np.array(d.qfrc_passive)[:3] == pytest.approx(F, rel=1e-9, abs=1e-12)
+    assert np.array(d.qfrc_passive)[3:6] == pytest.approx(T, rel=1e-9, abs=1e-12)
