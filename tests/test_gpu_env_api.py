@@ -722,3 +722,19 @@ def test_cartpole_config2_batch_1024_recovers_under_the_references_pid_as_a_devi
     assert np.abs(out["float64"][-1] - d.qpos).max() < 1e-9
     assert np.abs(out["float32"][-1] - d.qpos).max() < 1e-4          # closed loop, 300 steps: BASELINE's drift bound
     assert np.abs(out["float32"] - out["float64"]).max() < 1e-4
+
+
+def test_module_smoke_cli_runs_baseline_config_0():
+    """``python -m mujoco_template_amd pendulum.xml --steps 200 --zero`` = the reference's smoke CLI (mujoco_template/__main__.py:10-33) on
+    BASELINE config[0] (pendulum, ZeroController, Env.passive, 200 steps, batch 1), and the same flags with a batch."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--batch", "64"], ["--decim", "2"]):
+        r = subprocess.run([sys.executable, "-m", "mujoco_template_amd", MODELS["pendulum"], "--steps", "200", "--zero", *extra],
+                           capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Completed 200 steps." in r.stdout
+    r = subprocess.run([sys.executable, "-m", "mujoco_template_amd", MODELS["pendulum"], "--steps", "7"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "Completed 7 steps." in r.stdout, r.stdout + r.stderr

@@ -281,3 +281,17 @@ def test_binary_model_round_trip_and_names_through_the_c_abi(tmp_path):
     bad.write_bytes(b"not a model")
     with pytest.raises(ValueError, match="magic"):
         mj.MjModel.from_binary_path(str(bad))
+
+
+def test_module_smoke_cli_fails_loudly_without_a_gpu():
+    """No CPU fallback anywhere, the smoke CLI included: without a HIP device it exits non-zero and names the reason."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tests.conftest import MODELS
+
+    r = subprocess.run([sys.executable, "-m", "mujoco_template_amd", MODELS["pendulum"], "--steps", "3", "--zero"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    assert "HIP" in r.stderr or "device" in r.stderr.lower(), r.stderr[-400:]
