@@ -303,6 +303,19 @@ def main() -> None:
                        "dropped_contacts": int(counters["con_dropped"].sum()), "dropped_rows": int(counters["efc_dropped"].sum()),
                        "bad_state_resets": int(counters["warn_badqpos"].sum() + counters["warn_badqvel"].sum() + counters["warn_badqacc"].sum())},
         }
+        # second yardstick beside the contract's HBM roofline: what actually bounds this kernel is instruction issue.  VALU
+        # wave-instructions per env-step come from the committed PMC pass of the same kernel (SQ_INSTS_VALU, 100-step launches); peak = one
+        # wave64 VALU instruction per 2 cycles per SIMD-32 (MI355X_MICROARCH.md), 1024 SIMDs, 2.4 GHz
+        pmc = os.path.join(ROOT, "profiles", "r02_final_chunk100_summary.json")
+        if args.model == "humanoid" and sim.specialized and os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("SQ_INSTS_VALU"):
+                per_step = float(rec["SQ_INSTS_VALU"]) / 409600.0           # that pass: 4096 environments x 100 steps per launch
+                peak_issue = 1024 * 2.4e9 / 2.0
+                rate = per_step * count * avg_steps / (avg_ms * 1e-3)
+                out["issue_roofline"] = {"bound": "valu-issue", "achieved": rate, "peak": peak_issue, "unit": "wave-instructions/s", "frac": rate / peak_issue,
+                                         "valu_wave_instructions_per_env_step": per_step, "source": "profiles/r02_final_chunk100_summary.json (SQ_INSTS_VALU, separate --pmc pass)",
+                                         "note": "one wave alone issues a VALU instruction every 4 cycles, so two resident waves per SIMD can reach 1.0 only with no waits at all"}
         if weak_companion is not None:
             out["weak_scaling_companion"] = weak_companion
         if ws == 1 and not args.no_cpu_baseline:
