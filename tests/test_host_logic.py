@@ -16,6 +16,15 @@ from tests.conftest import BASE_XML
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> int:
+    """A rendezvous port nobody is listening on right now (fixed numbers collide with whatever an earlier run left behind)."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return int(sock.getsockname()[1])
+
+
 def test_philox_numpy_matches_oracle_c(oracle):
     m, d = oracle("humanoid")
     cm = m.compiled
@@ -129,7 +138,7 @@ def test_gloo_world_size_2_all_gather_obs(tmp_path):
         f"open(os.path.join({str(tmp_path)!r}, 'ok_%d' % rank), 'w').write('ok')\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29611", str(script)], capture_output=True, text=True, timeout=300, env=env)
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
 
@@ -154,7 +163,7 @@ def test_gloo_single_rank_group_issues_the_collective(tmp_path):
         "assert calls == [1] and out is not x and torch.equal(out, x)\n"
         "dist.destroy_process_group()\n"
         f"open(os.path.join({str(tmp_path)!r}, 'ok1'), 'w').write('ok')\n")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok1").exists()
