@@ -124,8 +124,15 @@ class LinearFeedbackController:
     ctrl_noise_std: np.ndarray | None = None     # [nu]
     perturbations: np.ndarray | None = None      # [nsteps, nu]: the reference's pre-drawn table, indexed by the step (mod nsteps)
     env_stride: int = 0                          # phase offset of the table per environment (0: every environment sees the same noise)
+    # optional clipped integrators (the yaw-integral term of the drone example, examples/drone2/main.py:437-452): per step and environment
+    #   z_j <- clip(z_j + (integ_rows[j] . dx) * timestep, +-integ_limit[j]);   ctrl -= sum_j z_j * integ_gain[j]
+    # A law with integrators carries state between steps: it is evaluated for the whole batch with numpy on the host mirrors (one
+    # vectorised call per step, no per-environment Python) and is NOT fused into rollout launches.
+    integ_rows: np.ndarray | None = None         # [ni, 2 nv]
+    integ_gain: np.ndarray | None = None         # [ni, nu]
+    integ_limit: np.ndarray | None = None        # [ni]
     capabilities: ControllerCapabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
-    device_ctrl_mode: str = "feedback"
+    device_ctrl_mode: str | None = "feedback"
     step_count: int = field(default=0)
 
     def prepare(self, model: Any, data: Any) -> None:
@@ -139,6 +146,19 @@ class LinearFeedbackController:
             raise ConfigError("LinearFeedbackController: K must be [nu, 2nv], ctrl0 [nu], qpos_goal [nq]")
         if (self.ctrl_noise_std is None) != (self.perturbations is None):
             raise ConfigError("LinearFeedbackController: ctrl_noise_std and perturbations go together")
+        self._integ = None
+        if self.integ_rows is not None:
+            self.integ_rows = np.atleast_2d(np.asarray(self.integ_rows, dtype=float))
+            self.integ_gain = np.atleast_2d(np.asarray(self.integ_gain, dtype=float))
+            self.integ_limit = np.atleast_1d(np.asarray(self.integ_limit, dtype=float))
+            ni = self.integ_rows.shape[0]
+            if self.integ_rows.shape != (ni, 2 * model.nv) or self.integ_gain.shape != (ni, model.nu) or self.integ_limit.shape != (ni,):
+                raise ConfigError("LinearFeedbackController: integ_rows [ni, 2nv], integ_gain [ni, nu], integ_limit [ni]")
+            self._integ = np.zeros((int(getattr(data, "batch", 1)), ni))
+            self._dt = float(model.opt.timestep)
+            self.device_ctrl_mode = None                 # stateful law: not fused, evaluated batched on the host mirrors
+        elif self.device_ctrl_mode is None:
+            self.device_ctrl_mode = "feedback"
         self.step_count = 0
         self._uploaded = None
 
@@ -150,6 +170,11 @@ class LinearFeedbackController:
             self._uploaded = sim
 
     def __call__(self, model: Any, data: Any, t: float) -> None:
+        if getattr(self, "_integ", None) is not None:    # stateful: the whole batch in numpy, integrators advanced once per call
+            rows = _ctrl_rows(data)
+            rows[...] = self.host_law(model, data, advance_integrators=True).reshape(rows.shape)
+            self.step_count += 1
+            return
         sim = data.sim
         data.push_host_edits()
         self.upload(sim)
@@ -157,8 +182,23 @@ class LinearFeedbackController:
         self.step_count += 1
         data.mark_device_newer()                 # ctrl now lives on the device: the mirrors refresh on the next read / step
 
-    def host_law(self, model: Any, data: Any, step: int | None = None) -> np.ndarray:
-        """The same law with numpy on the host mirrors; returns ctrl [batch, nu] (does not write it)."""
+    @staticmethod
+    def fold_yaw_shaping(K: np.ndarray, yaw_direction: np.ndarray, yaw_error_index: int, yaw_rate_index: int, *, proportional_gain: float = 0.0,
+                         derivative_gain: float = 0.0, control_scale: float = 1.0) -> np.ndarray:
+        """The drone example's yaw shaping (examples/drone2/main.py:430-466) folded into the gain matrix: the P and D terms add
+        ``yaw_direction (kp e_yaw + kd e_yawrate)^T`` to ``K``, and the control scale multiplies the component of ``K dx`` along the yaw
+        direction by ``control_scale`` - all linear in ``dx``, so ``ctrl0 - K' dx`` IS the shaped law (its integral term: ``integ_*``)."""
+        K = np.array(K, dtype=float)
+        y = np.asarray(yaw_direction, dtype=float).reshape(-1)
+        e = np.zeros(K.shape[1])
+        e[yaw_error_index] += proportional_gain
+        e[yaw_rate_index] += derivative_gain
+        Kp = K + np.outer(y, e)
+        return Kp + (control_scale - 1.0) * np.outer(y, y @ Kp) / float(y @ y)
+
+    def host_law(self, model: Any, data: Any, step: int | None = None, advance_integrators: bool = False) -> np.ndarray:
+        """The same law with numpy on the host mirrors; returns ctrl [batch, nu] (does not write it).  With integrators their state is
+        advanced only when ``advance_integrators`` is set (``__call__`` does); otherwise the update is evaluated on a copy."""
         from . import mj
 
         qpos, qvel = np.atleast_2d(np.asarray(data.qpos, dtype=float)), np.atleast_2d(np.asarray(data.qvel, dtype=float))
@@ -167,7 +207,13 @@ class LinearFeedbackController:
         hi = np.where(model.actuator_ctrllimited, model.actuator_ctrlrange[:, 1], np.inf)
         dq = np.zeros((B, model.nv))
         mj.mj_differentiatePos(model, dq, 1.0, np.ascontiguousarray(np.tile(self.qpos_goal, (B, 1))), np.ascontiguousarray(qpos))
-        u = self.ctrl0 - np.concatenate([dq, qvel - self.qvel_goal], axis=1) @ self.K.T
+        dx = np.concatenate([dq, qvel - self.qvel_goal], axis=1)
+        u = self.ctrl0 - dx @ self.K.T
+        if getattr(self, "_integ", None) is not None:
+            z = np.clip(self._integ + (dx @ self.integ_rows.T) * self._dt, -self.integ_limit, self.integ_limit)
+            if advance_integrators:
+                self._integ = z
+            u = u - z @ self.integ_gain
         if self.perturbations is not None:
             step = self.step_count if step is None else step
             idx = (step + np.arange(B) * self.env_stride) % len(self.perturbations)

@@ -738,3 +738,62 @@ def test_module_smoke_cli_runs_baseline_config_0():
         assert "Completed 200 steps." in r.stdout
     r = subprocess.run([sys.executable, "-m", "mujoco_template_amd", MODELS["pendulum"], "--steps", "7"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "Completed 7 steps." in r.stdout, r.stdout + r.stderr
+
+
+def test_drone_example_law_with_yaw_shaping_and_integral_matches_its_literal_restatement():
+    """The drone example's controller (examples/drone2/main.py:400-471): LQR delta, yaw P / D / I shaping along the yaw control direction
+    ``B[yaw_rate_row]``, yaw control scale, clip.  ``LinearFeedbackController.fold_yaw_shaping`` puts the P, D and scale terms into the gain
+    matrix and ``integ_*`` carry the clipped yaw integral; the result drives a batch exactly like the example's own per-step arithmetic
+    (restated literally below, one environment, Python) - and a law with integrator state is host-batched, never fused."""
+    rng = np.random.default_rng(5)
+    probe = mt.Env.from_xml_path(MODELS["drone2"], keyframe="hover", batch=1, dtype="float64")
+    m = probe.model
+    nu, nv = m.nu, m.nv
+    q_goal, u_hover = np.array(probe.data.qpos, dtype=float).ravel(), np.array(probe.data.ctrl, dtype=float).ravel()
+    A, Bm = mt.linearize_discrete(m, probe.data, eps=1e-6)
+    yaw_err, yaw_rate = 5, nv + 5                                   # pos_dim + rot_dim - 1, nv + pos_dim + rot_dim - 1 (main.py:379-383,432-433)
+    ydir = np.array(Bm[yaw_rate, :nu], dtype=float)
+    assert float(ydir @ ydir) > 0
+    K = rng.normal(size=(nu, 2 * nv)) * 0.05
+    kp, kd, ki, scale, lim, dt = 18.0, 4.5, 4.0, 6.0, 6.0, float(m.opt.timestep)      # the example's defaults (main.py:36-40)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+
+    class Literal:                                                   # the example's __call__, line by line, one environment
+        capabilities = mt.ControllerCapabilities(control_space=mt.ControlSpace.TORQUE)
+        def prepare(self, model, data):
+            self.integral = 0.0
+        def __call__(self, model, data, t):
+            dq = np.zeros(nv)
+            mj.mj_differentiatePos(model, dq, 1.0, q_goal, np.array(data.qpos, dtype=float).ravel())
+            dx = np.concatenate([dq, np.array(data.qvel, dtype=float).ravel()])
+            delta = K @ dx
+            self.integral = float(np.clip(self.integral + dx[yaw_err] * dt, -lim, lim))
+            delta = delta + ki * self.integral * ydir
+            delta = delta + (kp * dx[yaw_err] + kd * dx[yaw_rate]) * ydir
+            delta = delta + (scale - 1.0) * (float(delta @ ydir) / float(ydir @ ydir)) * ydir
+            data.ctrl[...] = np.clip(u_hover - delta, lo, hi).reshape(np.shape(data.ctrl))
+
+    # the integral term enters BEFORE the scale in the example: its gain along ydir is ki * scale after folding
+    Kf = mt.LinearFeedbackController.fold_yaw_shaping(K, ydir, yaw_err, yaw_rate, proportional_gain=kp, derivative_gain=kd, control_scale=scale)
+    rows = np.zeros((1, 2 * nv)); rows[0, yaw_err] = 1.0
+    ours = mt.LinearFeedbackController(K=Kf, ctrl0=u_hover, qpos_goal=q_goal, integ_rows=rows, integ_gain=(ki * scale * ydir)[None, :], integ_limit=[lim])
+
+    def make(ctl, batch):
+        env = mt.Env.from_xml_path(MODELS["drone2"], controller=ctl, keyframe="hover", batch=batch, dtype="float64")
+        q = np.atleast_2d(env.data.qpos)
+        q[:, 2] += 0.4
+        q[:, 3:7] = np.array([np.cos(0.15), 0.0, 0.0, np.sin(0.15)])            # 0.3 rad of yaw error: the integral and the clip matter
+        v = np.atleast_2d(env.data.qvel)
+        v[:, 5] = 0.5
+        return env
+    a, b = make(Literal(), 1), make(ours, 3)
+    assert not b.can_fuse() and ours.device_ctrl_mode is None
+    for _ in range(120):
+        a.step(return_obs=False)
+        b.step(return_obs=False)
+    qa, qb = np.array(a.data.qpos, dtype=float).ravel(), np.array(b.data.qpos, dtype=float)
+    assert np.abs(qb - qa).max() < 1e-10 and np.abs(np.array(b.data.ctrl) - np.array(a.data.ctrl).ravel()).max() < 1e-9
+    assert abs(ours._integ[0, 0]) > 1e-3 and np.abs(qa - q_goal).max() > 1e-2
+    # without integrators the same controller class is the fused device law again
+    plain = mt.LinearFeedbackController(K=Kf, ctrl0=u_hover, qpos_goal=q_goal)
+    assert make(plain, 2).can_fuse()
