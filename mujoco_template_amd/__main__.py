@@ -11,27 +11,31 @@ from .controllers import ZeroController
 from .env import Env
 from .runtime import run_passive_headless
 
+# (flag, argparse keywords): the reference's five, then the two this engine adds
+_FLAGS = (
+    ("xml", dict(help="MJCF file of the model")),
+    ("--steps", dict(type=int, default=300, help="physics steps to run")),
+    ("--zero", dict(action="store_true", help="drive with ZeroController (evaluated on the device)")),
+    ("--groups", dict(type=int, nargs="*", default=None, help="actuator groups left enabled (default: all)")),
+    ("--decim", dict(type=int, default=1, help="control decimation, >= 1")),
+    ("--batch", dict(type=int, default=1, help="independent replicas stepped together")),
+    ("--dtype", dict(default="float32", choices=("float32", "float64"), help="state precision on the device")),
+)
+
+
+def _run(opts: argparse.Namespace) -> int:
+    env = Env.from_xml_path(opts.xml, controller=ZeroController() if opts.zero else None, enabled_groups=opts.groups,
+                            control_decimation=opts.decim, batch=opts.batch, dtype=opts.dtype)
+    if opts.zero and opts.decim == 1:
+        return run_passive_headless(env, max_steps=opts.steps)             # fused launches
+    return sum(1 for _ in env.passive(max_steps=opts.steps))               # the reference's loop, one Env.step per step
+
 
 def main() -> None:
-    parser = argparse.ArgumentParser(description="Batched MuJoCo-template smoke test on MI355X (fail-fast)")
-    parser.add_argument("xml", help="Path to the MJCF XML")
-    parser.add_argument("--steps", type=int, default=300)
-    parser.add_argument("--zero", action="store_true", help="Use ZeroController (evaluated on the device)")
-    parser.add_argument("--groups", type=int, nargs="*", default=None, help="Enable only these actuator groups")
-    parser.add_argument("--decim", type=int, default=1, help="Control decimation (>=1)")
-    parser.add_argument("--batch", type=int, default=1, help="Independent replicas stepped together")
-    parser.add_argument("--dtype", default="float32", choices=["float32", "float64"])
-    args = parser.parse_args()
-
-    env = Env.from_xml_path(args.xml, controller=ZeroController() if args.zero else None, enabled_groups=args.groups,
-                            control_decimation=args.decim, batch=args.batch, dtype=args.dtype)
-    if args.zero and args.decim == 1:
-        steps = run_passive_headless(env, max_steps=args.steps)
-    else:
-        steps = 0
-        for _ in env.passive(max_steps=args.steps):
-            steps += 1
-    print(f"Completed {steps} steps.")
+    cli = argparse.ArgumentParser(description="Batched MuJoCo-template smoke test on MI355X (fail-fast)")
+    for flag, kw in _FLAGS:
+        cli.add_argument(flag, **kw)
+    print(f"Completed {_run(cli.parse_args())} steps.")
 
 
 if __name__ == "__main__":
