@@ -677,6 +677,31 @@ def test_humanoid_balances_on_one_leg_under_the_tutorial_lqr_and_fp32_tracks_flo
     assert up64 and up32
     assert max(dev[:5]) < 5e-5, dev                                                       # 1000 steps: BASELINE's 1e-4 with margin
     assert max(dev) < 1e-3, dev
+    # the float64 kernels against the ORACLE driven by the same law from Python (differentiatePos, K dx, noise row s, clip), 1000 closed-loop steps
+    from oracle import mjo
+    from mujoco_template_amd import mjcf as _mjcf
+
+    om = mjo.OracleModel(_mjcf.compile_xml_path(MODELS["humanoid"]))
+    od = mjo.OracleData(om)
+    od.reset(); od.qpos[:] = d["qpos0"]; od.qvel[:] = 0
+    lo, hi = model.actuator_ctrlrange[:, 0], model.actuator_ctrlrange[:, 1]
+    for s_ in range(1000):
+        dx = np.concatenate([od.differentiate_pos(d["qpos0"], od.qpos), od.qvel])
+        od.ctrl[:] = np.clip(d["ctrl0"] - d["K"] @ dx + d["ctrl_std"] * d["perturbations"][s_], lo, hi)
+        od.step()
+    ctl = mt.LinearFeedbackController(K=d["K"], ctrl0=d["ctrl0"], qpos_goal=d["qpos0"], ctrl_noise_std=d["ctrl_std"], perturbations=d["perturbations"], env_stride=0)
+    e64 = mt.Env.from_xml_path(MODELS["humanoid"], controller=ctl, keyframe=1, batch=1, dtype="float64")
+    e64.data.qpos[...] = d["qpos0"]
+    e64.data.qvel[...] = 0.0
+    e64.rollout(1000)
+    assert np.abs(np.array(e64.data.qpos, dtype=float).ravel() - od.qpos).max() < 1e-8      # same algorithm, different summation order, stabilised loop
+    ctl32 = mt.LinearFeedbackController(K=d["K"], ctrl0=d["ctrl0"], qpos_goal=d["qpos0"], ctrl_noise_std=d["ctrl_std"], perturbations=d["perturbations"], env_stride=0)
+    e32 = mt.Env.from_xml_path(MODELS["humanoid"], controller=ctl32, keyframe=1, batch=1, dtype="float32")
+    e32.data.qpos[...] = d["qpos0"]
+    e32.data.qvel[...] = 0.0
+    e32.rollout(1000)
+    drift = float(np.abs(np.array(e32.data.qpos, dtype=float).ravel() - od.qpos).max())
+    assert drift < 5e-5, drift          # BASELINE / north_star: fp32 qpos drift vs the CPU reference over 1000 steps <= 1e-4 (measured 5e-6)
     # the closed loop does not depend on how the batch is scheduled: two-wave kernel (512 environments), ticket map (4096), every environment
     # at its own phase of the noise table -> the first 512 environments are bitwise the same
     def closed_loop(batch):
