@@ -272,9 +272,17 @@ void choose_caps(const HostModel& h, int dtype, int lanes, int nconmax, int nefc
       // can ever be dropped (drone2: 20 contacts / 80+ rows when it lands flat); occupancy is not traded against that
       ne = h.nefc_alloc; nc = h.ncon_alloc;
     } else for (;; ne -= 8) {
-      nc = ne * 3 / 8; if (nc < 8) nc = 8; if (nc > h.ncon_alloc) nc = h.ncon_alloc;
-      Lay t = make_layout(h, nc > 0 ? nc : 1, ne > 0 ? ne : 1, dtype == MJB_F32 ? sizeof(float) : sizeof(double));
-      if ((size_t)(64 / lanes) * (size_t)t.bytes <= budget || ne <= 32) break;
+      // rows bind first (a frictional contact is four rows): for each row cap try 3/8 of it as contact cap and shave that down to a
+      // third before giving up rows (humanoid fp32: 64 rows / 23 contacts = 20 448 B, eight slices in 160 KB; 64 / 24 misses by 16 B)
+      int hi = ne * 3 / 8; if (hi < 8) hi = 8; if (hi > h.ncon_alloc) hi = h.ncon_alloc;
+      int lo = ne / 3; if (lo < 8) lo = 8; if (lo > hi) lo = hi;
+      bool fits = false;
+      for (nc = hi; nc >= lo; nc--) {
+        Lay t = make_layout(h, nc > 0 ? nc : 1, ne > 0 ? ne : 1, dtype == MJB_F32 ? sizeof(float) : sizeof(double));
+        if ((size_t)(64 / lanes) * (size_t)t.bytes <= budget) { fits = true; break; }
+      }
+      if (fits) break;
+      if (ne <= 32) { nc = hi; break; }
     }
   }
   if (nc < 1) nc = 1;
