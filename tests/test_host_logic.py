@@ -304,3 +304,21 @@ def test_module_smoke_cli_fails_loudly_without_a_gpu():
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0
     assert "HIP" in r.stderr or "device" in r.stderr.lower(), r.stderr[-400:]
+
+
+def test_default_caps_keep_eight_humanoids_per_cu():
+    """mjb_data_create's default caps (choose_caps): the largest row cap, then contact cap, whose LDS slice still lets eight fp32
+    environments share one CU's 160 KB (two waves per SIMD); small models hold their own worst case.  Read off the specialised
+    translation unit, which pins exactly these numbers (no GPU needed)."""
+    import re
+
+    from tests.conftest import MODELS
+
+    def caps(name):
+        src = mj.MjModel.from_xml_path(MODELS[name])._device_model().spec_source()
+        got = dict(re.findall(r"\(m\)\.(n(?:con|efc)_max) == (\d+)", src))
+        return int(got["nefc_max"]), int(got["ncon_max"]), int(re.search(r"\(L\)\.bytes == (\d+)", src).group(1))
+
+    ne, nc, lds = caps("humanoid")
+    assert (ne, nc) == (64, 23) and 8 * lds <= 160 * 1024 < 8 * (lds + 48)      # one more contact would not fit
+    assert caps("cartpole")[:2] == (28, 6) and caps("drone2")[:2] == (82, 20)    # the models' own worst cases: nothing can be dropped
