@@ -332,12 +332,14 @@ class _HostRandomCtrl:
     """A controller that lives in Python (no ``device_ctrl_mode``): the shape of every controller in the reference's examples —
     read ``data``, write ``data.ctrl`` in place, once per step (reference control.py:26-32)."""
 
-    def __init__(self, scale: float, seed: int = 0):
+    def __init__(self, scale: float, seed: int = 0, needs_linearization: bool = False):
         import numpy as np
 
         from mujoco_template_amd import ControllerCapabilities, ControlSpace
 
-        self.capabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE)
+        # needs_linearization: Env.step hands the controller's step a fresh discrete (A, B) every step (reference env.py:186-205 ->
+        # linearization.py:123-135 -> mjd_transitionFD), the shape of gain-scheduled / iLQR-style controllers
+        self.capabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE, needs_linearization=needs_linearization)
         self.scale, self.rng = scale, np.random.default_rng(seed)
 
     def prepare(self, model, data) -> None:
@@ -371,6 +373,21 @@ def host_loop(xml_path: str, scale: float, device: int, batch: int) -> dict:
             dt = time.perf_counter() - t
             out[f"batch{b}_return_obs_{return_obs}"] = {"value": b * nsteps / dt, "us_per_step": dt / nsteps * 1e6, "steps": nsteps}
         del env
+    # the same loop with a controller that asks for the linearisation every step (batch 1): k_fd + k_fd_combine + k_step per Env.step
+    env = Env.from_xml_path(xml_path, obs_spec=ObservationSpec(as_dict=False), controller=_HostRandomCtrl(scale, needs_linearization=True), batch=1,
+                            dtype="float32", device=device)
+    for _ in env.passive(max_steps=10, return_obs=False):
+        pass
+    t = time.perf_counter()
+    n = 0
+    for res in env.passive(max_steps=100, return_obs=False):
+        n += 1
+    dt = time.perf_counter() - t
+    A = res.info.get("A")
+    out["batch1_needs_linearization"] = {"value": n / dt, "us_per_step": dt / n * 1e6, "steps": n,
+                                         "A_shape": list(getattr(A, "shape", ())) if A is not None else None,
+                                         "what": "Env.step = centred finite-difference (A, B) of the step (float64, all columns side by side on the device) + controller + step"}
+    del env
     return out
 
 
@@ -411,6 +428,15 @@ def cpu_baseline(xml_path: str, scale: float) -> dict:
     dt1 = time.perf_counter() - t1
     _oracle_passive_loop(om, mjo, scale, 200, True)           # warm-up
     loop = {f"return_obs_{ro}": _oracle_passive_loop(om, mjo, scale, 20000, ro) for ro in (True, False)}
+    # ... and with the linearisation every step (mjd_transitionFD, centred, eps 1e-6, as the reference's Env.step does for such controllers)
+    od = mjo.OracleData(om)
+    od.transition_fd(1e-6, True)
+    tl = time.perf_counter()
+    nl = 40
+    for _ in range(nl):
+        od.transition_fd(1e-6, True)
+        od.step()
+    loop["needs_linearization"] = nl / (time.perf_counter() - tl)
     return {"value": nenv * nstep / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "single_core_value": 16 * nstep / dt1,
             "loop_faithful": {"unit": "env-steps/s", "cores": 1, **loop,
