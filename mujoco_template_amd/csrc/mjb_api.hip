@@ -1082,11 +1082,16 @@ static int transition_fd_impl(mjbData* d, double eps, int centered) {
                           : launch_fd<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, ncol, h.nv, h.nu, chunk, eps, d->fd_y, d->fd_valid, d->stream);
   if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("fd launch: ") + hipGetErrorString(e));
   long nthreads = (long)B * nin;
+  // a few environments (the reference's batch-1 loops with needs_linearization controllers): the combine kernel writes (A, B) straight
+  // into the pinned result blocks (device-visible) - no staging copies; larger batches keep the device blocks + one async copy each
+  const bool zero_copy = B * nx * (nx + (size_t)h.nu) * sizeof(double) <= (size_t)256 * 1024;
   hipLaunchKernelGGL(k_fd_combine<double>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, d->stream, (const DevModel<double>*)d->md_dev, d->batch, ncol, centered, eps,
-                     (const double*)d->fd_y, (const int*)d->fd_valid, d->fd_A, d->fd_B);
+                     (const double*)d->fd_y, (const int*)d->fd_valid, zero_copy ? d->fd_A_host : d->fd_A, zero_copy ? d->fd_B_host : d->fd_B);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(d->fd_A_host, d->fd_A, B * nx * nx * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-  if (h.nu > 0) HIPCHK(hipMemcpyAsync(d->fd_B_host, d->fd_B, B * nx * h.nu * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  if (!zero_copy) {
+    HIPCHK(hipMemcpyAsync(d->fd_A_host, d->fd_A, B * nx * nx * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    if (h.nu > 0) HIPCHK(hipMemcpyAsync(d->fd_B_host, d->fd_B, B * nx * h.nu * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+  }
   HIPCHK(hipStreamSynchronize(d->stream));
   return MJB_OK;
 }
