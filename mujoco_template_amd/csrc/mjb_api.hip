@@ -110,6 +110,11 @@ struct mjbData {
   // fd / jac scratch
   double *fd_y = nullptr, *fd_A = nullptr, *fd_B = nullptr;
   double *fd_A_host = nullptr, *fd_B_host = nullptr;          // pinned: the (A, B) blocks leave the device in one async copy each
+  // mjb_jac: persistent buffers (grown on demand) - the request (kinds | ids) in pinned memory the kernel reads directly, the result
+  // blocks pinned (small requests: written by the kernel itself) and on the device (large requests: one async copy each)
+  int* jac_req_pin = nullptr; int jac_req_cap = 0;
+  double *jac_pin[2] = {nullptr, nullptr}, *jac_dev[2] = {nullptr, nullptr};
+  size_t jac_pin_cap = 0, jac_dev_cap = 0;
   int* fd_valid = nullptr;
   // standalone feedback law (mjb_feedback_ctrl): optional noise (std [nu], table [nsteps, nu]) in both precisions, dx scratch for float64
   float *fb_noise_f[2] = {nullptr, nullptr};
@@ -653,6 +658,8 @@ void mjb_data_free(mjbData* d) {
   std::free(d->mirror_shadow);
   if (d->fd_A_host) (void)hipHostFree(d->fd_A_host);
   if (d->fd_B_host) (void)hipHostFree(d->fd_B_host);
+  if (d->jac_req_pin) (void)hipHostFree(d->jac_req_pin);
+  for (int k = 0; k < 2; k++) { if (d->jac_pin[k]) (void)hipHostFree(d->jac_pin[k]); if (d->jac_dev[k]) (void)hipFree(d->jac_dev[k]); }
   d->alloc.release();
   delete d;
 }
@@ -1127,25 +1134,45 @@ int mjb_jac(mjbData* d, int nreq, const int* kinds, const int* ids, double* jacp
   }
   HIPCHK(hipSetDevice(d->device));
   { int rc0 = refresh_options(d); if (rc0 != MJB_OK) return rc0; }
-  size_t n = (size_t)d->batch * nreq * 3 * h.nv;
-  double *op = nullptr, *orr = nullptr; int *dk = nullptr, *di = nullptr;
-  HIPCHK(hipMalloc((void**)&op, sizeof(double) * (n ? n : 1)));
-  HIPCHK(hipMalloc((void**)&orr, sizeof(double) * (n ? n : 1)));
-  HIPCHK(hipMalloc((void**)&dk, sizeof(int) * nreq));
-  HIPCHK(hipMalloc((void**)&di, sizeof(int) * nreq));
-  HIPCHK(hipMemcpy(dk, kinds, sizeof(int) * nreq, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(di, ids, sizeof(int) * nreq, hipMemcpyHostToDevice));
+  const size_t n = (size_t)d->batch * nreq * 3 * h.nv;
+  if (n == 0) return MJB_OK;
+  // persistent buffers instead of four hipMalloc / hipFree and four blocking copies per call (a controller with needs_jacobians calls this
+  // once per Env.step): request in pinned memory read by the kernel, results pinned, device staging only for large requests
+  if (nreq > d->jac_req_cap) {
+    if (d->jac_req_pin) (void)hipHostFree(d->jac_req_pin);
+    d->jac_req_pin = nullptr; d->jac_req_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&d->jac_req_pin, sizeof(int) * 2 * (size_t)nreq, hipHostMallocDefault));
+    d->jac_req_cap = nreq;
+  }
+  if (n > d->jac_pin_cap) {
+    for (int k = 0; k < 2; k++) { if (d->jac_pin[k]) (void)hipHostFree(d->jac_pin[k]); d->jac_pin[k] = nullptr; }
+    d->jac_pin_cap = 0;
+    for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&d->jac_pin[k], sizeof(double) * n, hipHostMallocDefault));
+    d->jac_pin_cap = n;
+  }
+  const bool zero_copy = 2 * n * sizeof(double) <= (size_t)256 * 1024;
+  if (!zero_copy && n > d->jac_dev_cap) {
+    for (int k = 0; k < 2; k++) { if (d->jac_dev[k]) (void)hipFree(d->jac_dev[k]); d->jac_dev[k] = nullptr; }
+    d->jac_dev_cap = 0;
+    for (int k = 0; k < 2; k++) HIPCHK(hipMalloc((void**)&d->jac_dev[k], sizeof(double) * n));
+    d->jac_dev_cap = n;
+  }
+  HIPCHK(hipStreamSynchronize(d->stream));                       // nothing queued may still be reading the previous request
+  std::memcpy(d->jac_req_pin, kinds, sizeof(int) * nreq);
+  std::memcpy(d->jac_req_pin + nreq, ids, sizeof(int) * nreq);
+  double *op = zero_copy ? d->jac_pin[0] : d->jac_dev[0], *orr = zero_copy ? d->jac_pin[1] : d->jac_dev[1];
+  const int *dk = d->jac_req_pin, *di = d->jac_req_pin + nreq;
   hipError_t e = d->dtype == MJB_F32 ? launch_jac<double, float>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->df, nreq, dk, di, op, orr, d->stream)
                                      : launch_jac<double, double>(d->G_fd, d->md_dev, d->Ld_dev, d->Ld, d->dd, nreq, dk, di, op, orr, d->stream);
-  int rc = MJB_OK;
-  if (e != hipSuccess) rc = fail(MJB_ERR_DEVICE, std::string("jac launch: ") + hipGetErrorString(e));
-  if (rc == MJB_OK && hipStreamSynchronize(d->stream) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac sync failed");
-  if (rc == MJB_OK && n) {
-    if (hipMemcpy(jacp_host, op, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac copy failed");
-    if (jacr_host && hipMemcpy(jacr_host, orr, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MJB_ERR_DEVICE, "jac copy failed");
+  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("jac launch: ") + hipGetErrorString(e));
+  if (!zero_copy) {
+    HIPCHK(hipMemcpyAsync(d->jac_pin[0], d->jac_dev[0], n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    if (jacr_host) HIPCHK(hipMemcpyAsync(d->jac_pin[1], d->jac_dev[1], n * sizeof(double), hipMemcpyDeviceToHost, d->stream));
   }
-  (void)hipFree(op); (void)hipFree(orr); (void)hipFree(dk); (void)hipFree(di);
-  return rc;
+  if (hipStreamSynchronize(d->stream) != hipSuccess) return fail(MJB_ERR_DEVICE, "jac sync failed");
+  std::memcpy(jacp_host, d->jac_pin[0], n * sizeof(double));
+  if (jacr_host) std::memcpy(jacr_host, d->jac_pin[1], n * sizeof(double));
+  return MJB_OK;
 }
 
 
