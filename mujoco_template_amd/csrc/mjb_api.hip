@@ -112,6 +112,7 @@ struct mjbData {
   double *fd_A_host = nullptr, *fd_B_host = nullptr;          // pinned: the (A, B) blocks leave the device in one async copy each
   // mjb_jac: persistent buffers (grown on demand) - the request (kinds | ids) in pinned memory the kernel reads directly, the result
   // blocks pinned (small requests: written by the kernel itself) and on the device (large requests: one async copy each)
+  void* io_pin = nullptr; size_t io_pin_cap = 0;               // pinned staging of mjb_get_array / mjb_set_array (grown on demand)
   int* jac_req_pin = nullptr; int jac_req_cap = 0;
   double *jac_pin[2] = {nullptr, nullptr}, *jac_dev[2] = {nullptr, nullptr};
   size_t jac_pin_cap = 0, jac_dev_cap = 0;
@@ -542,17 +543,30 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
   return MJB_OK;
 }
 
+// pinned staging block of the array getters / setters: the copies run on the data's stream straight to / from pinned memory (no pageable
+// staging inside the runtime, no per-call temporary), the widening / narrowing conversion happens between it and the caller's array
+int ensure_io_pin(mjbData* d, size_t bytes) {
+  if (bytes <= d->io_pin_cap) return MJB_OK;
+  if (d->io_pin) (void)hipHostFree(d->io_pin);
+  d->io_pin = nullptr; d->io_pin_cap = 0;
+  const size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 4;
+  HIPCHK(hipHostMalloc(&d->io_pin, cap, hipHostMallocDefault));
+  d->io_pin_cap = cap;
+  return MJB_OK;
+}
+
 int copy_out(mjbData* d, const ArrayInfo& ai, double* host_out) {
   size_t n = (size_t)d->batch * ai.per_env;
   if (n == 0) return MJB_OK;
+  const bool wide = ai.kind == 1 || (ai.kind == 0 && d->dtype == MJB_F64);
+  if (!wide && ai.kind != 0) return fail(MJB_ERR_ARG, "integer array requested as float64");
+  const size_t bytes = n * (wide ? sizeof(double) : sizeof(float));
+  int rc = ensure_io_pin(d, bytes);
+  if (rc != MJB_OK) return rc;
+  HIPCHK(hipMemcpyAsync(d->io_pin, ai.ptr, bytes, hipMemcpyDeviceToHost, d->stream));   // ordered behind whatever the stream still runs
   HIPCHK(hipStreamSynchronize(d->stream));
-  if (ai.kind == 1 || (ai.kind == 0 && d->dtype == MJB_F64)) {
-    HIPCHK(hipMemcpy(host_out, ai.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
-  } else if (ai.kind == 0) {
-    std::vector<float> tmp(n);
-    HIPCHK(hipMemcpy(tmp.data(), ai.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) host_out[i] = (double)tmp[i];
-  } else return fail(MJB_ERR_ARG, "integer array requested as float64");
+  if (wide) std::memcpy(host_out, d->io_pin, bytes);
+  else { const float* src = (const float*)d->io_pin; for (size_t i = 0; i < n; i++) host_out[i] = (double)src[i]; }
   return MJB_OK;
 }
 }  // namespace
@@ -659,6 +673,7 @@ void mjb_data_free(mjbData* d) {
   if (d->fd_A_host) (void)hipHostFree(d->fd_A_host);
   if (d->fd_B_host) (void)hipHostFree(d->fd_B_host);
   if (d->jac_req_pin) (void)hipHostFree(d->jac_req_pin);
+  if (d->io_pin) (void)hipHostFree(d->io_pin);
   for (int k = 0; k < 2; k++) { if (d->jac_pin[k]) (void)hipHostFree(d->jac_pin[k]); if (d->jac_dev[k]) (void)hipFree(d->jac_dev[k]); }
   d->alloc.release();
   delete d;
@@ -704,14 +719,15 @@ int mjb_set_array(mjbData* d, const char* name, const double* host_in) {
   size_t n = (size_t)d->batch * ai.per_env;
   if (n == 0) return MJB_OK;
   HIPCHK(hipSetDevice(d->device));
-  HIPCHK(hipStreamSynchronize(d->stream));
-  if (ai.kind == 1 || (ai.kind == 0 && d->dtype == MJB_F64)) {
-    HIPCHK(hipMemcpy(ai.ptr, host_in, n * sizeof(double), hipMemcpyHostToDevice));
-  } else if (ai.kind == 0) {
-    std::vector<float> tmp(n);
-    for (size_t i = 0; i < n; i++) tmp[i] = (float)host_in[i];
-    HIPCHK(hipMemcpy(ai.ptr, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
-  } else return fail(MJB_ERR_ARG, "integer arrays are read-only");
+  const bool wide = ai.kind == 1 || (ai.kind == 0 && d->dtype == MJB_F64);
+  if (!wide && ai.kind != 0) return fail(MJB_ERR_ARG, "integer arrays are read-only");
+  const size_t bytes = n * (wide ? sizeof(double) : sizeof(float));
+  int rc = ensure_io_pin(d, bytes);
+  if (rc != MJB_OK) return rc;
+  if (wide) std::memcpy(d->io_pin, host_in, bytes);
+  else { float* dst = (float*)d->io_pin; for (size_t i = 0; i < n; i++) dst[i] = (float)host_in[i]; }
+  HIPCHK(hipMemcpyAsync(ai.ptr, d->io_pin, bytes, hipMemcpyHostToDevice, d->stream));    // ordered behind the launches already queued
+  HIPCHK(hipStreamSynchronize(d->stream));                                               // the staging block is free again on return
   return MJB_OK;
 }
 
