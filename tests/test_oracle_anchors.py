@@ -632,3 +632,26 @@ def test_inertia_box_fluid_forces_on_the_falling_drone(oracle):
     assert np.abs(F).max() > 0.01                                   # a real force (tens of millinewtons to newtons)
     assert np.array(d.qfrc_passive)[:3] == pytest.approx(F, rel=1e-9, abs=1e-12)
     assert np.array(d.qfrc_passive)[3:6] == pytest.approx(T, rel=1e-9, abs=1e-12)
+
+
+def test_humanoid_joint_springs_and_dampers_from_the_nested_default_classes(oracle):
+    """Passive joint forces of the humanoid, with the per-joint stiffness / damping transcribed BY HAND from the nested default classes of
+    humanoid.xml:67-101 (base 1 / 0.2; joint_big 10 / 5 for abdomen_y, abdomen_x and the six hip joints; joint_big_stiff 20 / 5 for
+    abdomen_z; ankle_y 6, ankle_x 3, elbow 0 on the base damping): qfrc_passive = -k q - d qvel per hinge (springref 0), nothing on the
+    free joint (no fluid in this model, no tendon springs).  Pins the class inheritance of the compiler and the passive-force stage."""
+    m, d = oracle("humanoid")
+    leg = [(10, 5), (10, 5), (10, 5), (1, 0.2), (6, 0.2), (3, 0.2)]              # hip_x, hip_z, hip_y, knee, ankle_y, ankle_x
+    arm = [(1, 0.2), (1, 0.2), (0, 0.2)]                                         # shoulder1, shoulder2, elbow
+    kd = np.array([(20, 5), (10, 5), (10, 5)] + leg + leg + arm + arm, dtype=float)   # abdomen z, y, x | right leg | left leg | right arm | left arm
+    assert kd.shape == (21, 2)
+    rng = np.random.default_rng(11)
+    d.reset()
+    d.qpos[2] += 3.0                                                             # off the floor
+    q = rng.uniform(-0.3, 0.3, 21)
+    v = rng.normal(size=27)
+    d.qpos[7:] = q
+    d.qvel[:] = v
+    d.forward()
+    fp = np.array(d.qfrc_passive)
+    assert np.abs(fp[:6]).max() == 0.0
+    assert fp[6:] == pytest.approx(-kd[:, 0] * q - kd[:, 1] * v[6:], rel=1e-12, abs=1e-12)
