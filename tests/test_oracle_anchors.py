@@ -655,3 +655,24 @@ def test_humanoid_joint_springs_and_dampers_from_the_nested_default_classes(orac
     fp = np.array(d.qfrc_passive)
     assert np.abs(fp[:6]).max() == 0.0
     assert fp[6:] == pytest.approx(-kd[:, 0] * q - kd[:, 1] * v[6:], rel=1e-12, abs=1e-12)
+
+
+def test_humanoid_motor_gears_clamp_and_armature(oracle):
+    """Actuation of the humanoid with the gears transcribed by hand from humanoid.xml:203-223 (actuator i drives dof 6 + i):
+    qfrc_actuator = gear * clip(ctrl, -1, 1) (ctrlrange of the motor default class), zero on the free joint.  M is symmetric and, with the
+    joint default's armature of 0.01 (humanoid.xml:67) added to every hinge dof, its spectrum stays above that armature."""
+    m, d = oracle("humanoid")
+    leg, arm = [40, 40, 120, 80, 20, 20], [20, 20, 40]
+    gear = np.array([40, 40, 40] + leg + leg + arm + arm, dtype=float)
+    rng = np.random.default_rng(3)
+    d.reset()
+    d.qpos[2] += 3.0
+    u = rng.uniform(-1.6, 1.6, 21)                                               # a third of them beyond the ctrlrange
+    d.ctrl[:] = u
+    d.forward()
+    fa = np.array(d.qfrc_actuator)
+    assert np.abs(fa[:6]).max() == 0.0
+    assert fa[6:] == pytest.approx(gear * np.clip(u, -1.0, 1.0), rel=1e-13, abs=1e-13)
+    assert (np.abs(u) > 1).sum() >= 4
+    M = np.array(d.qM).reshape(27, 27)
+    assert np.allclose(M, M.T, atol=1e-13) and np.linalg.eigvalsh(M).min() > 0.01 - 1e-12    # armature bounds the spectrum from below
