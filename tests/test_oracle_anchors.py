@@ -676,3 +676,27 @@ def test_humanoid_motor_gears_clamp_and_armature(oracle):
     assert (np.abs(u) > 1).sum() >= 4
     M = np.array(d.qM).reshape(27, 27)
     assert np.allclose(M, M.T, atol=1e-13) and np.linalg.eigvalsh(M).min() > 0.01 - 1e-12    # armature bounds the spectrum from below
+
+
+def test_humanoid_joint_ranges_in_radians_from_the_default_classes(oracle):
+    """Joint limits transcribed by hand (degrees, the compiler's default angle unit) from humanoid.xml:69-101,120-176 - classes hip_x / hip_z /
+    hip_y / knee / ankle / shoulder / elbow, explicit ranges on the abdomen - and what they become: jnt_range in radians, every hinge
+    limited.  Then the limit row itself on one joint: an elbow 1 degree past its upper limit gives exactly one extra row with
+    efc_pos = -1 degree in radians."""
+    m, d = oracle("humanoid")
+    cm = m.compiled
+    leg = [(-30, 10), (-60, 35), (-150, 20), (-160, 2), (-50, 50), (-50, 50)]
+    arm = [(-85, 60), (-85, 60), (-100, 50)]
+    deg = np.array([(-45, 45), (-75, 30), (-35, 35)] + leg + leg + arm + arm, dtype=float)
+    rng_ = np.reshape(cm.arrays["jnt_range"], (-1, 2))
+    assert rng_[1:] == pytest.approx(np.deg2rad(deg), abs=1e-12)
+    assert np.asarray(cm.arrays["jnt_limited"])[1:].all() and not np.asarray(cm.arrays["jnt_limited"])[0]
+    d.reset(); d.qpos[2] += 3.0
+    d.forward()
+    n0 = d.counters()["nefc"]
+    elbow_r = 7 + 3 + 6 + 6 + 2                                 # qpos address of elbow_right: free joint 7, abdomen 3, two legs 6 + 6, two shoulder joints
+    d.qpos[elbow_r] = np.deg2rad(51.0)                          # 1 degree past the upper limit (the arm touches nothing there)
+    d.forward()
+    assert d.counters()["nefc"] == n0 + 1
+    pos = np.array(d.efc_pos)[: n0 + 1]
+    assert np.isclose(pos, -np.deg2rad(1.0), atol=1e-12).sum() == 1
