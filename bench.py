@@ -332,14 +332,15 @@ class _HostRandomCtrl:
     """A controller that lives in Python (no ``device_ctrl_mode``): the shape of every controller in the reference's examples —
     read ``data``, write ``data.ctrl`` in place, once per step (reference control.py:26-32)."""
 
-    def __init__(self, scale: float, seed: int = 0, needs_linearization: bool = False):
+    def __init__(self, scale: float, seed: int = 0, needs_linearization: bool = False, needs_jacobians: tuple = ()):
         import numpy as np
 
         from mujoco_template_amd import ControllerCapabilities, ControlSpace
 
         # needs_linearization: Env.step hands the controller's step a fresh discrete (A, B) every step (reference env.py:186-205 ->
         # linearization.py:123-135 -> mjd_transitionFD), the shape of gain-scheduled / iLQR-style controllers
-        self.capabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE, needs_linearization=needs_linearization)
+        self.capabilities = ControllerCapabilities(control_space=ControlSpace.TORQUE, needs_linearization=needs_linearization,
+                                                   needs_jacobians=tuple(needs_jacobians))
         self.scale, self.rng = scale, np.random.default_rng(seed)
 
     def prepare(self, model, data) -> None:
@@ -388,6 +389,20 @@ def host_loop(xml_path: str, scale: float, device: int, batch: int) -> dict:
                                          "A_shape": list(getattr(A, "shape", ())) if A is not None else None,
                                          "what": "Env.step = centred finite-difference (A, B) of the step (float64, all columns side by side on the device) + controller + step"}
     del env
+    # ... and one that asks for two Jacobians every step (operational-space shape: reference env.py:186-205 -> jacobians.py:26-83)
+    if "humanoid" in os.path.basename(xml_path):
+        env = Env.from_xml_path(xml_path, obs_spec=ObservationSpec(as_dict=False), batch=1, dtype="float32", device=device,
+                                controller=_HostRandomCtrl(scale, needs_jacobians=("subtreecom:torso", "bodycom:foot_left")))
+        for _ in env.passive(max_steps=10, return_obs=False):
+            pass
+        t = time.perf_counter()
+        n = 0
+        for res in env.passive(max_steps=200, return_obs=False):
+            n += 1
+        dt = time.perf_counter() - t
+        out["batch1_needs_jacobians"] = {"value": n / dt, "us_per_step": dt / n * 1e6, "steps": n, "requests": ["subtreecom:torso", "bodycom:foot_left"],
+                                         "keys": sorted(k for k in res.info if "jac" in k.lower())}
+        del env
     return out
 
 
@@ -437,6 +452,14 @@ def cpu_baseline(xml_path: str, scale: float) -> dict:
         od.transition_fd(1e-6, True)
         od.step()
     loop["needs_linearization"] = nl / (time.perf_counter() - tl)
+    if om.compiled.nbody > 10:                # humanoid: the two Jacobians of the host_loop leg (subtree COM of body 1, body COM of body 10) + step
+        tj = time.perf_counter()
+        nj = 5000
+        for _ in range(nj):
+            od.jac(3, 1)
+            od.jac(2, 10)
+            od.step()
+        loop["needs_jacobians"] = nj / (time.perf_counter() - tj)
     return {"value": nenv * nstep / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "single_core_value": 16 * nstep / dt1,
             "loop_faithful": {"unit": "env-steps/s", "cores": 1, **loop,
