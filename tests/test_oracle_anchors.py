@@ -700,3 +700,24 @@ def test_humanoid_joint_ranges_in_radians_from_the_default_classes(oracle):
     assert d.counters()["nefc"] == n0 + 1
     pos = np.array(d.efc_pos)[: n0 + 1]
     assert np.isclose(pos, -np.deg2rad(1.0), atol=1e-12).sum() == 1
+
+
+def test_drone_rotor_wrench_from_hand_transcribed_sites_and_gears(oracle):
+    """Site transmissions of the drone (x2.xml:15,33-40,68-80): each rotor pushes along its site's z axis (gear 0 0 1) and adds a reaction
+    torque about that axis (+0.11 for the counter-clockwise class, -0.11 for the clockwise one; rotors 1, 3 are cw, 2, 4 ccw).  At the
+    identity orientation the generalized actuator force on the free joint is the plain wrench about the body origin:
+    force (0, 0, sum u), torque sum r_i x (0, 0, u_i) + (0, 0, sum g_i u_i), with the site positions transcribed by hand."""
+    m, d = oracle("drone2")
+    r = np.array([[-0.14, -0.18, 0.05], [-0.14, 0.18, 0.05], [0.14, 0.18, 0.08], [0.14, -0.18, 0.08]])
+    g = np.array([-0.11, 0.11, -0.11, 0.11])
+    u = np.array([2.0, 5.5, 9.0, 12.5])                        # inside ctrlrange 0 .. 13
+    d.reset(); d.qpos[2] += 5.0
+    d.ctrl[:] = u
+    d.forward()
+    F = np.array([0.0, 0.0, u.sum()])
+    T = sum(np.cross(r[i], [0.0, 0.0, u[i]]) for i in range(4)) + np.array([0.0, 0.0, float(g @ u)])
+    fa = np.array(d.qfrc_actuator)
+    assert fa[:3] == pytest.approx(F, abs=1e-12) and fa[3:6] == pytest.approx(T, abs=1e-12)
+    d.ctrl[:] = [20.0, -3.0, 13.0, 0.0]                        # clamped to 0 .. 13
+    d.forward()
+    assert np.array(d.qfrc_actuator)[2] == pytest.approx(13.0 + 0.0 + 13.0 + 0.0, abs=1e-12)
