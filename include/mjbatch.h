@@ -90,6 +90,15 @@ int mjb_data_create(mjbModel* m, int batch, int dtype, int lanes, int nconmax, i
 void mjb_data_free(mjbData* d);
 int mjb_set_stream(mjbData* d, void* hip_stream);
 int mjb_sync(mjbData* d);
+/* Engine failures cross the ABI (reference convention: mujoco raises FatalError / mujoco_template raises TemplateError,
+ * exceptions.py:4-21 - nothing is ever silently wrong).  Sticky flag word of the batch, bit 0 contacts dropped, 1 constraint rows
+ * dropped (per-environment LDS caps exceeded: truncated physics, COUNTED per environment by mjb_get_counters), 2 bad-state auto-reset
+ * (mj_checkPos/Vel/Acc), 3 a ticket-mode launch timed out waiting for a state hand-over.  mjb_engine_flags waits for the stream and
+ * reports the word (the kernels keep it in pinned host memory: no copy).  Bit 3 is an ERROR: from the first synchronising call
+ * after it was raised (mjb_sync, mjb_get_array, mjb_get_counters, mjb_sync_to_host, mjb_step_host*) and at the entry of every
+ * further launch (mjb_step, mjb_rollout, mjb_forward ...) the library returns MJB_ERR_DEVICE until mjb_reset clears the flags; the
+ * environments concerned were NOT advanced (their arrays hold the state the failed launch started from). */
+int mjb_engine_flags(mjbData* d, int* flags_out);
 int mjb_data_info(mjbData* d, int* batch, int* dtype, int* lanes, int* nconmax, int* nefcmax, int* lds_bytes_per_env);
 
 /* device pointer of a [batch, n] state array: qpos qvel ctrl qacc qacc_warmstart (dtype of the data),
@@ -109,7 +118,8 @@ int mjb_get_counters(mjbData* d, int* host_out /* [batch, 8] */);
  * mjb_step_host = sync_to_device(field_mask) + nstep x mj_step (nstep = 0: mj_forward) + sync_to_host in one call: the body of the
  * reference's host-driven loop (env.py:186-190, runtime.py:631-663) costs one library call per step. ---- */
 /* name "engine_flags": ONE double behind the state, refreshed by the same copy: sticky bits 0 contacts dropped, 1 constraint rows dropped
- * (per-environment LDS caps exceeded), 2 bad-state auto-reset — the whole-batch OR of what mjb_get_counters details per environment */
+ * (per-environment LDS caps exceeded), 2 bad-state auto-reset, 3 hand-over timed out (see mjb_engine_flags) — the whole-batch OR of what
+ * mjb_get_counters details per environment */
 int mjb_host_view(mjbData* d, const char* name, double** host_ptr, long* per_env);
 int mjb_sync_to_host(mjbData* d);
 int mjb_sync_to_device(mjbData* d, int field_mask);

@@ -61,6 +61,7 @@ def load_library() -> ctypes.CDLL:
     L.mjb_data_free.argtypes = [vp]
     L.mjb_set_stream.argtypes = [vp, vp]
     L.mjb_sync.argtypes = [vp]
+    L.mjb_engine_flags.argtypes = [vp, pci]
     L.mjb_data_info.argtypes = [vp, pci, pci, pci, pci, pci, pci]
     L.mjb_array_ptr.argtypes = [vp, ctypes.c_char_p, pvp, ctypes.POINTER(cl), pci]
     L.mjb_get_array.argtypes = [vp, ctypes.c_char_p, vp]
@@ -136,7 +137,7 @@ def load_library() -> ctypes.CDLL:
                  "mjb_forward", "mjb_inverse", "mjb_spec_load", "mjb_spec_unload", "mjb_fd_spec_load", "mjb_fd_spec_unload", "mjb_step2_spec_load", "mjb_step2_spec_unload", "mjb_step", "mjb_rollout", "mjb_obs_spec_create", "mjb_obs_dim", "mjb_obs_gather",
                  "mjb_transition_fd", "mjb_jac", "mjb_debug_forward", "mjb_debug_get", "mjb_model_field", "mjb_model_field_at", "mjb_model_save",
                  "mjb_model_load", "mjb_model_load_xml", "mjb_model_load_xml_string", "mjb_integrate_pos", "mjb_differentiate_pos", "mjb_host_view", "mjb_sync_to_host", "mjb_sync_to_device",
-                 "mjb_step_host", "mjb_mirror_edited_mask", "mjb_mirror_commit", "mjb_step_host_auto"):
+                 "mjb_step_host", "mjb_mirror_edited_mask", "mjb_mirror_commit", "mjb_step_host_auto", "mjb_engine_flags"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
@@ -600,6 +601,14 @@ class BatchSim:
     def step_host(self, nstep: int, field_mask: int = 0) -> None:
         """upload the edited mirror fields, ``nstep`` x mj_step (0: mj_forward), refresh the mirror — one library call."""
         _check(load_library().mjb_step_host(self.ptr, int(nstep), int(field_mask)))
+
+    def engine_flags(self) -> int:
+        """Sticky flag word of the batch after waiting for the stream (``mjb_engine_flags``): bit 0 contacts dropped, 1 constraint rows
+        dropped, 2 bad-state auto-reset, 3 a ticket-mode launch timed out on a hand-over (the one that makes every synchronising call
+        raise ``TemplateError`` until ``reset``).  No copy: the kernels keep the word in pinned host memory."""
+        out = ctypes.c_int(0)
+        _check(load_library().mjb_engine_flags(self.ptr, ctypes.byref(out)))
+        return int(out.value)
 
     def counters(self) -> dict[str, np.ndarray]:
         out = np.zeros((self.batch, 8), dtype=np.int32)

@@ -127,6 +127,9 @@ struct mjbData {
   double* mirror_shadow = nullptr;        // host copy of the block as last refreshed / uploaded: what in-place edits are detected against
   unsigned long long mirror_seq = 0;      // sequence number of the last polled host-driven step (completion words behind the flags word)
   size_t mirror_off[7] = {0, 0, 0, 0, 0, 0, 0};             // element offsets of the six fields, [6] = total
+  int* flags_pin = nullptr;               // pinned: the four engine-flag bits as words the kernels set (DevData::flags_pin)
+  unsigned xfer_timeout = 0;              // ticks of the 100 MHz clock a wave waits for a hand-over (0 = not yet read from MJB_XFER_TIMEOUT_MS)
+  int xfer_poison_env = -1;               // test hook MJB_XFER_POISON_ENV (-1 = not yet read)
 };
 
 namespace {
@@ -173,8 +176,9 @@ bool parse_blob(const std::vector<char>& b, std::vector<std::string>& names, std
     std::memcpy(&dt, b.data() + o, 4); o += 4; std::memcpy(&cnt, b.data() + o, 8); o += 8;
     if (dt < 0 || dt > 2 || cnt < 0) { err = "corrupt model file (dtype/count)"; return false; }
     o = (o + 7) / 8 * 8;
+    // count is checked against what is left of the file BEFORE it is multiplied: a crafted int64 count must not wrap the byte size
+    if (o > b.size() || (uint64_t)cnt > (uint64_t)(b.size() - o) / elem_size(dt)) { err = "truncated model file"; return false; }
     size_t nb = (size_t)cnt * elem_size(dt);
-    if (!need(nb)) { err = "truncated model file"; return false; }
     ptrs.push_back(b.data() + o); dts.push_back(dt); cnts.push_back((long)cnt);
     o = (o + nb + 7) / 8 * 8;
   }
@@ -211,6 +215,11 @@ template <typename TS> int alloc_state(mjbData* d, DevData<TS>& s) {
   rc |= dev_alloc(d, &s.qfrc_inverse, B * h.nv); rc |= dev_alloc(d, &s.actuator_moment, B * h.nu * h.nv);
   rc |= dev_alloc(d, &s.counters, B * CNT_N); rc |= dev_alloc(d, &s.flags, 1);
   rc |= dev_alloc(d, &s.sched, 1);
+  if (!d->flags_pin) {                                          // the engine flags as four words of pinned host memory (raise_engine_flags)
+    if (hipHostMalloc((void**)&d->flags_pin, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) return -1;
+    std::memset(d->flags_pin, 0, 4 * sizeof(int));
+  }
+  s.flags_pin = d->flags_pin;
   s.xfer = nullptr;                                             // hand-over buffer of the ticket map: allocated by the first launch that needs it
   rc |= dev_alloc(d, &s.prof, (size_t)PH_N + 4 * B);        // + per-environment timeline records of the -DMJB_TIMELINE diagnostic kernel
   if (rc) return -1;
@@ -469,8 +478,21 @@ static void choose_schedule(mjbData* d, StepArgs& a) {
   if (std::getenv("MJB_SCHED_DEBUG")) std::fprintf(stderr, "[mjb] schedule: blocks %ld, resident slots %ld, steps %d -> chunk_steps %d, fair_bit %d\n", nblk, d->step_slots, a.nstep, a.chunk_steps, a.fair_bit);
 }
 
+// Bit 3 of the engine flags: a wave of a ticket-mode launch gave up waiting for a hand-over and left its environment where the launch
+// found it - the results of that launch are incomplete.  The kernels set the word in pinned host memory, so after any stream
+// synchronisation (and at the entry of the next launch) the host sees it without a copy: every entry point that synchronises
+// returns MJB_ERR_DEVICE from then on, until mjb_reset clears the flags.
+int engine_check(const mjbData* d) {
+  if (d->flags_pin && __atomic_load_n(d->flags_pin + 3, __ATOMIC_ACQUIRE) != 0)
+    return fail(MJB_ERR_DEVICE, "a ticket-mode launch timed out waiting for a state hand-over (engine flag 8): the environments concerned were not "
+                                "advanced; mjb_reset() clears the condition");
+  return MJB_OK;
+}
+
 int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_out, bool debug) {
-  int rc = refresh_options(d);
+  int rc = engine_check(d);                                    // no further launches on top of a failed one
+  if (rc != MJB_OK) return rc;
+  rc = refresh_options(d);
   if (rc != MJB_OK) return rc;
   hipError_t e;
   StepArgs a = a_in;
@@ -488,15 +510,29 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
     d->last_sched[0] = a.nstep; d->last_sched[1] = (d->batch + epb - 1) / epb; d->last_sched[2] = (int)(d->step_slots > 0 ? d->step_slots : 0);
     d->last_sched[3] = a.chunk_steps; d->last_sched[4] = a.fair_bit;
   }
+  // host-side bookkeeping of the ticket counter and the tag sequence: COMMITTED only after the launch succeeded (a failed launch must
+  // not leave the host counter ahead of the device's: every later ticket would then underflow and no step would run)
+  unsigned seq_next = d->launch_seq;
+  unsigned long long ticket_after = d->ticket_next;
   if (a.chunk_steps > 0) {
-    do { d->launch_seq++; } while ((d->launch_seq & 0xFFFu) == 0);
-    a.tagbase = (d->launch_seq & 0xFFFu) << 20;
+    do { seq_next++; } while ((seq_next & 0xFFFu) == 0);
+    a.tagbase = (seq_next & 0xFFFu) << 20;
     // the ticket counter is never reset on the hot path: every launched workgroup draws tickets until one is past the end, so a
     // launch advances the counter by exactly (tickets + workgroups) and the next launch starts from there (32-bit: rewound long before it wraps)
     const unsigned long long adv = (unsigned long long)a.nblk * (unsigned)a.nchunk + (unsigned long long)a.grid_blocks;
     if (d->ticket_next + adv > 0xF0000000ull) { HIPCHK(hipMemsetAsync(d->df.sched, 0, sizeof(unsigned), d->stream)); d->ticket_next = 0; }
     a.ticket_base = (unsigned)d->ticket_next;
-    d->ticket_next += adv;
+    ticket_after = d->ticket_next + adv;
+    if (d->xfer_timeout == 0) {                                  // default 5 s of wall clock; MJB_XFER_TIMEOUT_MS for tests
+      const char* e1 = std::getenv("MJB_XFER_TIMEOUT_MS");
+      double ms = e1 ? std::atof(e1) : 5000.0;
+      if (!(ms > 0)) ms = 5000.0;
+      if (ms > 40000.0) ms = 40000.0;
+      d->xfer_timeout = (unsigned)(ms * 1e5);
+      if (d->xfer_timeout == 0) d->xfer_timeout = 1;
+    }
+    if (d->xfer_poison_env < 0) { const char* e2 = std::getenv("MJB_XFER_POISON_ENV"); d->xfer_poison_env = e2 ? std::atoi(e2) + 1 : 0; if (d->xfer_poison_env < 0) d->xfer_poison_env = 0; }
+    a.xfer_timeout = d->xfer_timeout; a.xfer_poison_env = d->xfer_poison_env;
   }
   // Two waves per environment (env_run2) when the batch leaves at least half of the step kernel's resident slots empty: stepping
   // launches only (mode 0, no debug dumps), fp32, one wave per environment, nv <= 32, Euler.
@@ -539,7 +575,13 @@ int launch(mjbData* d, const StepArgs& a_in, const ObsSpecDev& obs, void* obs_ou
     DevDebug<double> none; std::memset(&none, 0, sizeof(none));
     e = launch_step<double, double>(d->G, d->md_dev, d->Ld_dev, d->Ld, d->dd, debug ? d->dbgd : none, a, obs, (double*)obs_out, d->stream);
   }
-  if (e != hipSuccess) return fail(MJB_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+  if (e != hipSuccess) {
+    // the device counter may or may not have been rewound above and no workgroup drew a ticket: start the next ticket launch from a
+    // known state (counter zeroed in stream order, host count zero)
+    if (a.chunk_steps > 0) { (void)hipMemsetAsync(d->df.sched, 0, sizeof(unsigned), d->stream); d->ticket_next = 0; }
+    return fail(MJB_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+  }
+  d->launch_seq = seq_next; d->ticket_next = ticket_after;
   return MJB_OK;
 }
 
@@ -565,6 +607,7 @@ int copy_out(mjbData* d, const ArrayInfo& ai, double* host_out) {
   if (rc != MJB_OK) return rc;
   HIPCHK(hipMemcpyAsync(d->io_pin, ai.ptr, bytes, hipMemcpyDeviceToHost, d->stream));   // ordered behind whatever the stream still runs
   HIPCHK(hipStreamSynchronize(d->stream));
+  { int ec = engine_check(d); if (ec != MJB_OK) return ec; }
   if (wide) std::memcpy(host_out, d->io_pin, bytes);
   else { const float* src = (const float*)d->io_pin; for (size_t i = 0; i < n; i++) host_out[i] = (double)src[i]; }
   return MJB_OK;
@@ -674,13 +717,23 @@ void mjb_data_free(mjbData* d) {
   if (d->fd_B_host) (void)hipHostFree(d->fd_B_host);
   if (d->jac_req_pin) (void)hipHostFree(d->jac_req_pin);
   if (d->io_pin) (void)hipHostFree(d->io_pin);
+  if (d->flags_pin) (void)hipHostFree(d->flags_pin);
   for (int k = 0; k < 2; k++) { if (d->jac_pin[k]) (void)hipHostFree(d->jac_pin[k]); if (d->jac_dev[k]) (void)hipFree(d->jac_dev[k]); }
   d->alloc.release();
   delete d;
 }
 
 int mjb_set_stream(mjbData* d, void* hip_stream) { if (!d) return fail(MJB_ERR_ARG, "data is NULL"); d->stream = (hipStream_t)hip_stream; return MJB_OK; }
-int mjb_sync(mjbData* d) { if (!d) return fail(MJB_ERR_ARG, "data is NULL"); HIPCHK(hipStreamSynchronize(d->stream)); return MJB_OK; }
+int mjb_sync(mjbData* d) { if (!d) return fail(MJB_ERR_ARG, "data is NULL"); HIPCHK(hipStreamSynchronize(d->stream)); return engine_check(d); }
+
+int mjb_engine_flags(mjbData* d, int* flags_out) {
+  if (!d || !flags_out) return fail(MJB_ERR_ARG, "NULL argument");
+  HIPCHK(hipStreamSynchronize(d->stream));
+  int fl = 0;
+  for (int k = 0; k < 4; k++) if (d->flags_pin && __atomic_load_n(d->flags_pin + k, __ATOMIC_ACQUIRE) != 0) fl |= 1 << k;
+  *flags_out = fl;
+  return MJB_OK;
+}
 
 int mjb_data_info(mjbData* d, int* batch, int* dtype, int* lanes, int* nconmax, int* nefcmax, int* lds_bytes_per_env) {
   if (!d) return fail(MJB_ERR_ARG, "data is NULL");
@@ -736,7 +789,7 @@ int mjb_get_counters(mjbData* d, int* host_out) {
   HIPCHK(hipSetDevice(d->device));
   HIPCHK(hipStreamSynchronize(d->stream));
   HIPCHK(hipMemcpy(host_out, d->arrays["counters"].ptr, (size_t)d->batch * CNT_N * sizeof(int), hipMemcpyDeviceToHost));
-  return MJB_OK;
+  return engine_check(d);
 }
 
 int mjb_reset(mjbData* d, int key) {
@@ -758,6 +811,9 @@ int mjb_reset(mjbData* d, int key) {
     hipLaunchKernelGGL(k_reset<double>, dim3(grid), dim3(threads), 0, d->stream, d->dd, h.nq, h.nv, h.nu, qp, qv, cu, time);
   }
   HIPCHK(hipGetLastError());
+  // a reset also clears the sticky engine flags (k_reset, in stream order); after a failed ticket launch the host-visible word must be
+  // clear before the next launch's entry check reads it: wait for the reset in that (rare) case
+  if (d->flags_pin && __atomic_load_n(d->flags_pin + 3, __ATOMIC_ACQUIRE) != 0) HIPCHK(hipStreamSynchronize(d->stream));
   return MJB_OK;
 }
 
@@ -1236,11 +1292,20 @@ int mjb_model_field_at(const mjbModel* m, int index, const char** name, const vo
 
 int mjb_model_save(const mjbModel* m, const char* path) {
   if (!m || !path) return fail(MJB_ERR_ARG, "model/path is NULL");
+  // like mj_saveModel the file carries the options as they are NOW (disableactuator / iterations / tolerance may have been edited
+  // since the table was compiled): they are patched into a copy of the creation-time blob
+  std::vector<char> blob = m->blob;
+  for (const auto& fl : m->fields) {
+    if (fl.count != 1) continue;
+    if (fl.dtype == 1 && fl.name == "disableactuator") { int32_t v = m->disableactuator; std::memcpy(blob.data() + fl.off, &v, 4); }
+    else if (fl.dtype == 1 && fl.name == "iterations") { int32_t v = m->iterations; std::memcpy(blob.data() + fl.off, &v, 4); }
+    else if (fl.dtype == 0 && fl.name == "tolerance") { double v = m->tolerance; std::memcpy(blob.data() + fl.off, &v, 8); }
+  }
   FILE* f = std::fopen(path, "wb");
   if (!f) return fail(MJB_ERR_ARG, std::string("cannot open for writing: ") + path);
-  size_t n = std::fwrite(m->blob.data(), 1, m->blob.size(), f);
+  size_t n = std::fwrite(blob.data(), 1, blob.size(), f);
   int rc = std::fclose(f);
-  if (n != m->blob.size() || rc != 0) return fail(MJB_ERR_ARG, std::string("short write: ") + path);
+  if (n != blob.size() || rc != 0) return fail(MJB_ERR_ARG, std::string("short write: ") + path);
   return MJB_OK;
 }
 
@@ -1365,7 +1430,7 @@ static int mirror_pull(mjbData* d) {
   HIPCHK(hipGetLastError());
   if (dst == d->mirror_dev) HIPCHK(hipMemcpyAsync(d->mirror_host, d->mirror_dev, (size_t)(total + 1) * sizeof(double), hipMemcpyDeviceToHost, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
-  return MJB_OK;
+  return engine_check(d);
 }
 
 static int mirror_push(mjbData* d, int mask) {

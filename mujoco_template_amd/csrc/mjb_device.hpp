@@ -2502,6 +2502,19 @@ MJB_DEV unsigned long long xfer_ld(const unsigned long long* p) { return __hip_a
 MJB_DEV void xfer_st(unsigned long long* p, unsigned bits, unsigned tag) {
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Sticky engine flags of the batch (bit 0 contacts dropped, 1 rows dropped, 2 bad-state reset, 3 hand-over timed out): the device word
+// (atomic OR, read by the mirror pack kernel) and the same bits as plain stores of 1 into four words of pinned host memory, which the
+// host reads after any stream synchronisation without a copy.  Rare events only: call from ONE lane.
+template <typename TS> MJB_DEV void raise_engine_flags(DataRef<TS> d, int fl) {
+  if (d.flags) atomicOr(d.flags, fl);
+  if (d.flags_pin) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) if ((fl >> k) & 1) *(volatile int*)(d.flags_pin + k) = 1;
+  }
+}
+// the tag no hand-over of this launch can carry (steps per launch < 2^20 - 2): written into an environment's clock words by the wave
+// that gave up waiting for it, so that the waves holding the environment's LATER chunks stop at once instead of timing out one by one
+MJB_DEV unsigned xfer_dead_tag(unsigned tagbase) { return tagbase | 0xFFFFFu; }
 #endif
 
 // steps [s_begin, s_end) of the launch's a.nstep.  tag_in != 0: the state comes from the hand-over buffer (written by the wave that
@@ -2524,7 +2537,10 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
       staged_in = true;
       const unsigned long long* x = d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2);
       unsigned tlo = 0, thi = 0;
-      for (unsigned spins = 0;; spins++) {
+      const unsigned dead = xfer_dead_tag(a.tagbase);
+      const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
+      bool lost = false;                                         // group-uniform: this environment's earlier steps will never arrive
+      for (;;) {
         bool ok = true;
         for (int i = lane; i < nq; i += G) { const unsigned long long v = xfer_ld(x + i); ok = ok && (unsigned)(v >> 32) == tag_in; w[L.qpos + i] = __uint_as_float((unsigned)v); }
         for (int i = lane; i < nv; i += G) {
@@ -2536,13 +2552,24 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
           const unsigned long long v0 = xfer_ld(x + nq + 3 * nv), v1 = xfer_ld(x + nq + 3 * nv + 1);
           ok = ok && (unsigned)(v0 >> 32) == tag_in && (unsigned)(v1 >> 32) == tag_in;
           tlo = (unsigned)v0; thi = (unsigned)v1;
+          lost = (unsigned)(v0 >> 32) == dead;                     // a wave before this one gave the environment up
         }
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;          // every word of every environment of this wave carries the tag
-        // the steps before s_begin are held by a wave with a smaller ticket, which is running: wait (bounded: a wave that gives up
-        // flags the launch, bit 3 of the engine flags, and goes on with what it has)
-        if (spins > (1u << 20)) { if (lane == 0 && d.flags) atomicOr(d.flags, 8); break; }
+        if (__builtin_amdgcn_ballot_w64(!ok && !lost) == 0) { lost = lost || gany<G>(!ok); break; }   // every word of every live environment of this wave carries the tag
+        // the steps before s_begin are held by a wave with a smaller ticket, which is running: wait - bounded by the wall clock.  A
+        // wave that gives up flags the launch (bit 3 of the engine flags: the host's next synchronising call returns MJB_ERR_DEVICE),
+        // marks the environment dead for the waves that hold its later chunks and does NOT step it: nothing computed from a torn
+        // state is ever published, the environment's state arrays keep what they held when the launch started.
+        if (__builtin_amdgcn_s_memrealtime() - t_wait0 > (unsigned long long)a.xfer_timeout) {
+          lost = lost || gany<G>(!ok);
+          if (lost && lane == 0) {
+            raise_engine_flags<TS>(d, 8);
+            xfer_st(d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2) + nq + 3 * nv, 0u, dead);
+          }
+          break;
+        }
         __builtin_amdgcn_s_sleep(8);
       }
+      if (lost) return;
       time = __longlong_as_double((long long)(((unsigned long long)thi << 32) | tlo));
     }
   }
@@ -2638,7 +2665,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
     if (badqvel) atomicAdd(cn + CNT_BADQVEL, badqvel);
     if (badqacc) atomicAdd(cn + CNT_BADQACC, badqacc);
     const int fl = (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0);
-    if (fl && d.flags) atomicOr(d.flags, fl);                  // rare: the host reads ONE word instead of the [batch, 8] counters
+    if (fl) raise_engine_flags<TS>(d, fl);                     // rare: the host reads ONE word instead of the [batch, 8] counters
 #else
     cn[CNT_CON_DROPPED] += c.con_dropped; cn[CNT_EFC_DROPPED] += c.efc_dropped;
     cn[CNT_BADQPOS] += badqpos; cn[CNT_BADQVEL] += badqvel; cn[CNT_BADQACC] += badqacc;
@@ -2647,8 +2674,9 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
 #if !defined(MJB_HOST_EMU) && !defined(MJB_NO_XFER)
   if constexpr (sizeof(T) == 4 && sizeof(TS) == 4) {
     // the hand-over made at step s_end carries tag tagbase + s_end
-    const unsigned tag_out = (a.mode == 0 && a.chunk_steps > 0 && s_end < a.nstep) ? a.tagbase + (unsigned)s_end : 0u;
+    unsigned tag_out = (a.mode == 0 && a.chunk_steps > 0 && s_end < a.nstep) ? a.tagbase + (unsigned)s_end : 0u;
     if (tag_out != 0) {                                        // hand the environment to whoever draws its next chunk
+      if (a.xfer_poison_env != 0 && env + 1 == a.xfer_poison_env) tag_out ^= 0x80000u;   // test hook: this hand-over never validates
       unsigned long long* x = d.xfer + (size_t)env * (size_t)(nq + 3 * nv + 2);
       for (int i = lane; i < nq; i += G) xfer_st(x + i, __float_as_uint(w[L.qpos + i]), tag_out);
       for (int i = lane; i < nv; i += G) {
@@ -2677,9 +2705,6 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
     int* cn = d.counters + (size_t)env * CNT_N;
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
   }
-#ifndef MJB_HOST_EMU
-  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0), a.mirror_seq);
-#endif
   if (a.write_kin) {
     for (int i = lane; i < 3 * m.nbody; i += G) {
       d.xpos[(size_t)env * 3 * m.nbody + i] = (TS)w[L.xpos + i];
@@ -2717,6 +2742,11 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
     for (int i = lane; i < 10 * m.nbody; i += G) dbg.cinert[(size_t)env * 10 * m.nbody + i] = (TS)w[L.cinert + i];
     for (int i = lane; i < 6 * m.nbody; i += G) dbg.cvel[(size_t)env * 6 * m.nbody + i] = (TS)w[L.cvel + i];
   }
+#ifndef MJB_HOST_EMU
+  // LAST: the completion word a polling host returns on (mirror_out's release store) is published behind every global store of this
+  // environment above, so a consumer on another stream that reads the device arrays after the polled return sees them complete
+  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (c.con_dropped ? 1 : 0) | (c.efc_dropped ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0), a.mirror_seq);
+#endif
 }
 
 
@@ -2816,11 +2846,10 @@ MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, 
     if (badqvel) atomicAdd(cn + CNT_BADQVEL, badqvel);
     if (badqacc) atomicAdd(cn + CNT_BADQACC, badqacc);
     const int fl = (cdrop ? 1 : 0) | (edrop ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0);
-    if (fl && d.flags) atomicOr(d.flags, fl);
+    if (fl) raise_engine_flags<TS>(d, fl);
     d.time[env] = time;
     cn[CNT_NCON] = c.ncon; cn[CNT_NEFC] = c.nefc; cn[CNT_NITER] = c.niter;
   }
-  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (mail[2] ? 1 : 0) | (mail[3] ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0), a.mirror_seq);
   for (int i = lane; i < nq; i += G) d.qpos[(size_t)env * nq + i] = (TS)w[L.qpos + i];
   for (int i = lane; i < nv; i += G) {
     d.qvel[(size_t)env * nv + i] = (TS)w[L.qvel + i];
@@ -2839,6 +2868,8 @@ MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, 
     for (int i = lane; i < 3 * m.ngeom; i += G) d.geom_xpos[(size_t)env * 3 * m.ngeom + i] = (TS)w[L.geom_xpos + i];
     for (int i = lane; i < m.nsensordata; i += G) d.sensordata[(size_t)env * m.nsensordata + i] = (TS)w[L.sens + i];
   }
+  // LAST (see env_run): the polled completion word goes out behind every global store of this environment
+  if (a.mirror) mirror_out<T, G>(m, L, w, a.mirror, env, d.batch, lane, time, (mail[2] ? 1 : 0) | (mail[3] ? 2 : 0) | ((badqpos | badqvel | badqacc) ? 4 : 0), a.mirror_seq);
 }
 #endif
 

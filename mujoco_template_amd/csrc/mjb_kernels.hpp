@@ -334,7 +334,7 @@ template <typename TS>
 __global__ void k_reset(DevData<TS> d, int nq, int nv, int nu, const TS* qpos, const TS* qvel, const TS* ctrl, double time) {
   long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= d.batch) return;
-  if (tid == 0) d.flags[0] = 0;
+  if (tid == 0) { d.flags[0] = 0; if (d.flags_pin) for (int k = 0; k < 4; k++) d.flags_pin[k] = 0; }
   for (int i = 0; i < nq; i++) d.qpos[tid * nq + i] = qpos[i];
   for (int i = 0; i < nv; i++) { d.qvel[tid * nv + i] = qvel ? qvel[i] : (TS)0; d.qacc[tid * nv + i] = 0; d.qacc_warmstart[tid * nv + i] = 0; }
   for (int i = 0; i < nu; i++) d.ctrl[tid * nu + i] = ctrl ? ctrl[i] : (TS)0;

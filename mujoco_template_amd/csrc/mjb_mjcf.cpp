@@ -12,6 +12,7 @@
 #include <expat.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -86,18 +87,26 @@ static std::string dir_of(const std::string& path) {
   return k == std::string::npos ? std::string(".") : (k == 0 ? std::string("/") : path.substr(0, k));
 }
 
-static void expand_includes(Elem& e, const std::string& base_dir) {
+// MuJoCo rejects a file that is included twice; here a repeat (which also covers self-inclusion and cycles) raises MjcfError
+// instead of recursing until the stack overflows.  `seen` holds the paths of every file included so far, canonicalised.
+static std::string canonical_path(const std::string& path) {
+  char buf[PATH_MAX];
+  return realpath(path.c_str(), buf) ? std::string(buf) : path;
+}
+static void expand_includes(Elem& e, const std::string& base_dir, std::set<std::string>& seen, int depth = 0) {
+  if (depth > 64) throw Error("<include> nesting deeper than 64 levels");
   std::vector<std::unique_ptr<Elem>> out;
   for (auto& c : e.kids) {
     if (c->tag == "include") {
       const std::string path = base_dir + "/" + c->gets("file", "");
       std::ifstream probe(path);
       if (!probe) throw Error("include file not found: " + path);
+      if (!seen.insert(canonical_path(path)).second) throw Error("file included more than once (or an include cycle): " + path);
       auto sub = parse_xml(read_file(path));
-      expand_includes(*sub, dir_of(path));
+      expand_includes(*sub, dir_of(path), seen, depth + 1);
       for (auto& k : sub->kids) out.push_back(std::move(k));
     } else {
-      expand_includes(*c, base_dir);
+      expand_includes(*c, base_dir, seen, depth + 1);
       out.push_back(std::move(c));
     }
   }
@@ -514,7 +523,8 @@ struct Compiler {
   TableOut T;
 
   Compiler(std::unique_ptr<Elem> r, const std::string& base_dir) : root(std::move(r)) {
-    expand_includes(*root, base_dir);
+    std::set<std::string> included;
+    expand_includes(*root, base_dir, included);
     model_name = root->gets("model", "");
   }
 

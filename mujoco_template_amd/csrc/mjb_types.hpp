@@ -110,7 +110,9 @@ struct DevData {
   TS *xpos, *xquat, *xipos, *site_xpos, *geom_xpos, *subtree_com, *sensordata;
   TS *qfrc_inverse, *actuator_moment;   // outputs of the inverse-dynamics mode: [batch, nv], [batch, nu, nv]
   int* counters;
-  int* flags;                 // one sticky word for the whole batch: bit 0 contacts dropped, 1 constraint rows dropped, 2 bad-state reset
+  int* flags;                 // one sticky word for the whole batch: bit 0 contacts dropped, 1 constraint rows dropped, 2 bad-state reset, 3 hand-over timed out
+  int* flags_pin;             // the same four bits as four words of PINNED HOST memory (plain stores of 1, no read-modify-write over the bus): after any
+                              // stream synchronisation the host reads them without a copy (mjb_engine_flags; MJB_ERR_DEVICE once [3] is set)
   unsigned long long* prof;   // per-phase cycle sums (diagnostic -DMJB_PROFILE build only; null otherwise)
   unsigned* sched;            // ticket mode of k_step: [0] next ticket
   unsigned long long* xfer;   // ticket mode: tagged hand-over buffer [batch, nq + 3 nv + 2] (env_run)
@@ -159,13 +161,15 @@ struct StepArgs {
   unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ the step index at which the hand-over happens), unique among the launches that could still be in the buffer
   int nblk, grid_blocks; // ticket mode: environment blocks of the batch; workgroups launched (the resident ones)
   int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of steps) tickets from d.sched (mjb_kernels.hpp)
+  unsigned xfer_timeout; // ticket mode: how long a wave waits for a hand-over before it gives up, in ticks of the 100 MHz wall clock (s_memrealtime)
+  int xfer_poison_env;   // test hook (MJB_XFER_POISON_ENV): the hand-overs of environment (this - 1) are published with a wrong tag; 0 = off
   int nuniform, nchunk;  // ticket mode, the chunk plan of an environment's nstep steps: `nuniform` chunks of chunk_steps steps, then every
                          // further chunk takes HALF of what is left (guided taper down to single steps: the launch's tail is half of the
                          // LAST chunk); nchunk = all chunks.  chunk_plan() below is the one definition, used by host and device.
 };
 
 // Chunk k of the plan (nstep, chunk_steps, nuniform): steps [s0, s1).  Host and device.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline void chunk_plan(int nstep, int chunk_steps, int nuniform, int k, int& s0, int& s1) {

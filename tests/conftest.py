@@ -43,6 +43,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Measured parity errors next to their tolerances.  Every fp32 tolerance of the GPU suite goes through ``measured()``: the value is
+# kept (dumped to gpurun_out/parity_measured.json when the session ends - the numbers DESIGN.md §7 quotes) and printed in the assertion
+# message; tolerances are set to <= 3x what was measured.  MJB_PARITY_RECORD_ONLY=1 records without asserting (a calibration run).
+_MEASURED: dict = {}
+
+
+def measured(key: str, value, tol: float, what: str = "") -> None:
+    value = float(value)
+    prev = _MEASURED.get(key)
+    _MEASURED[key] = {"measured": max(value, prev["measured"]) if prev else value, "tol": float(tol)}
+    if os.environ.get("MJB_PARITY_RECORD_ONLY") == "1":
+        return
+    assert value <= tol, f"{key}: measured {value:.3e} > tolerance {tol:.3e} {what}"
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MEASURED:
+        return
+    import json
+
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_measured.json"), "w") as f:
+            json.dump(dict(sorted(_MEASURED.items())), f, indent=1)
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def models():
     return MODELS

@@ -15,10 +15,22 @@ pytestmark = pytest.mark.gpu
 from mujoco_template_amd._capi import CTRL_KEEP, CTRL_RANDOM, CTRL_ZERO, BatchSim, DeviceModel  # noqa: E402
 from mujoco_template_amd import mjcf  # noqa: E402
 from oracle import mjo  # noqa: E402
-from tests.conftest import BASE_XML, MODELS  # noqa: E402
+from tests.conftest import BASE_XML, MODELS, measured  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SCALE = {"pendulum": 1.0, "cartpole": 0.005, "humanoid": 1.0, "drone2": 0.3, "base": 1.0}
+
+# fp32 tolerances, per model: <= 3x the error measured on an MI355X (gpurun_out/parity_measured.json of the round-3 calibration run,
+# quoted in DESIGN.md §7); every one goes through tests.conftest.measured(), which prints the measured value when it fails.
+FWD_TOL32 = {"pendulum": 2e-5, "cartpole": 2e-5, "drone2": 2e-5, "humanoid": 2e-5, "base": 2e-5}                    # forward phases, relative
+STEP_TOL32 = {"pendulum": (2e-6, 2e-3), "cartpole": (2e-6, 2e-3), "drone2": (2e-6, 2e-3), "humanoid": (2e-6, 2e-3), "base": (2e-6, 2e-3)}
+GOLD_TQ32 = {"pendulum": 2e-4, "cartpole": 2e-4, "humanoid": 2e-4, "drone2": 2e-4}                                  # 40 free-running steps
+GOLD_AB64 = {"pendulum": 1e-5, "cartpole": 1e-5, "humanoid": 1e-4, "drone2": 1e-5}
+GOLD_AB32 = {"pendulum": 1e-3, "cartpole": 1e-3, "humanoid": 1e-1, "drone2": 1e-3}
+FD_TOL = {"pendulum": 5e-5, "cartpole": 5e-5, "drone2": 5e-5, "humanoid": 5e-5, "base": 5e-5}
+FD_CONTACT_TOL = {"float64": 1e-3, "float32": 1e-3}
+CFG5_TOL = {"hover100": 1e-4, "tf_q": 2e-6, "tf_v": 2e-3, "land_q": 2e-6, "land_v": 2e-3, "land_free_median": 1e-3}
+FB_TOL32 = {"drone2": (5e-4, 5e-3), "cartpole": (5e-4, 5e-3)}
 
 
 @pytest.fixture(scope="module")
@@ -55,13 +67,15 @@ def test_forward_phases_match_oracle(world, name, dtype):
     sim.debug_forward()
     for e, od in enumerate(ods):
         od.qpos[:] = q[e]; od.qvel[:] = v[e]; od.ctrl[:] = u[e]; od.forward()
-    tol = 1e-10 if dtype == "float64" else 2e-5
+    tol = 1e-10 if dtype == "float64" else FWD_TOL32[name]
+    worst = 0.0
     for key in ("qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qacc_smooth", "qfrc_constraint"):
         ref = np.stack([getattr(od, key) for od in ods])
         got = sim.debug_get(key)
-        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), key
+        worst = max(worst, np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
     ref = np.stack([od.qacc for od in ods])
-    assert np.abs(sim.get("qacc") - ref).max() <= tol * max(1.0, np.abs(ref).max())
+    worst = max(worst, np.abs(sim.get("qacc") - ref).max() / max(1.0, np.abs(ref).max()))
+    measured(f"forward_phases/{name}/{dtype}", worst, tol, "(relative to the largest entry of each array)")
     for key in ("xpos", "xipos", "site_xpos", "geom_xpos", "subtree_com"):
         ref = np.stack([getattr(od, key) for od in ods])
         if ref.size == 0:
@@ -190,7 +204,8 @@ def test_float64_free_running_matches_oracle(world, name, steps):
 
 @pytest.mark.parametrize("name,steps", [("pendulum", 100), ("cartpole", 100), ("drone2", 100), ("humanoid", 100), ("base", 100)])
 def test_fp32_teacher_forced_single_step(world, name, steps):
-    """fp32 product path from identical states: one-step |dqpos| <= 2e-6, |dqvel| <= 2e-3 * max(1,|qvel|)."""
+    """fp32 product path from identical states (teacher-forced along the oracle trajectory): one-step |dqpos| and
+    |dqvel| / max(1, |qvel|) per model, tolerances = 3x what was measured (STEP_TOL32)."""
     cm, om, dm = world(name)
     B = 8
     sim = BatchSim(dm, B, dtype="float32")
@@ -209,8 +224,8 @@ def test_fp32_teacher_forced_single_step(world, name, steps):
         qo, vo = np.stack([od.qpos for od in ods]), np.stack([od.qvel for od in ods])
         worst_q = max(worst_q, np.abs(sim.get("qpos") - qo).max())
         worst_v = max(worst_v, (np.abs(sim.get("qvel") - vo) / np.maximum(1.0, np.abs(vo))).max())
-    assert worst_q <= 2e-6, worst_q
-    assert worst_v <= 2e-3, worst_v
+    measured(f"teacher_forced_step/{name}/qpos", worst_q, STEP_TOL32[name][0])
+    measured(f"teacher_forced_step/{name}/qvel_rel", worst_v, STEP_TOL32[name][1])
 
 
 @pytest.mark.parametrize("name", ["pendulum", "cartpole", "humanoid", "drone2"])
@@ -218,7 +233,7 @@ def test_against_committed_golden(world, name):
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     cm, om, dm = world(name)
     B, nstep, seed, scale = g["qpos0"].shape[0], int(g["nstep"]), int(g["seed"]), float(g["scale"])
-    for dtype, tq in (("float64", 1e-8), ("float32", 2e-4)):
+    for dtype, tq in (("float64", 1e-8), ("float32", GOLD_TQ32[name])):
         sim = BatchSim(dm, B, dtype=dtype)
         sim.set("qpos", g["qpos0"]); sim.set("qvel", g["qvel0"])
         sim.rollout(1, CTRL_RANDOM, seed=seed, ctrl_scale=scale)       # writes the step-0 ctrl
@@ -230,8 +245,22 @@ def test_against_committed_golden(world, name):
         ref = g["fwd_qacc"]
         assert np.abs(sim.get("qacc") - ref).max() <= ft * max(1.0, np.abs(ref).max())
         assert sim.counters()["nefc"].tolist() == g["fwd_nefc"].tolist()
+        # the fixtures' (A, B): mjd_transitionFD (centred, eps 1e-6) at the state the forward pass above left (warm start = its solution).
+        # float64 data: the device linearises about the very state of the fixture; fp32 data: about that state rounded to fp32
+        # (the FD arithmetic is float64 either way), so only float64 is held to the fixture
+        A, Bm = sim.transition_fd(1e-6, True)
+        ea = np.abs(A - g["A"]).max() / max(1.0, np.abs(g["A"]).max())
+        eb = np.abs(Bm - g["B"]).max() / max(1.0, np.abs(g["B"]).max()) if cm.nu else 0.0
+        if dtype == "float64":
+            measured(f"golden/{name}/AB_float64", max(ea, eb), GOLD_AB64[name], "(relative to the largest entry)")
+        else:
+            measured(f"golden/{name}/AB_fp32_state", max(ea, eb), GOLD_AB32[name], "(fp32-rounded state, float64 FD; relative)")
         sim.rollout(nstep, CTRL_RANDOM, seed=seed, ctrl_scale=scale)
-        assert np.abs(sim.get("qpos") - g["qposT"]).max() <= tq, dtype
+        err = np.abs(sim.get("qpos") - g["qposT"]).max()
+        if dtype == "float64":
+            assert err <= tq, (dtype, err)
+        else:
+            measured(f"golden/{name}/qposT_fp32", err, tq)
 
 
 def test_cartpole_config2_drift(world):
@@ -355,11 +384,11 @@ def test_transition_fd_matches_oracle(world, name, B, eps):
     A, Bm = sim.transition_fd(eps, True)
     q32, v32, u32 = sim.get("qpos"), sim.get("qvel"), sim.get("ctrl")     # the fp32-rounded state the device linearised about
     worst = 0.0
-    for e in range(min(B, 8)):
+    for e in range(B):                                       # EVERY environment (config 4: all 512 cart-poles)
         od.reset(); od.qpos[:] = q32[e]; od.qvel[:] = v32[e]; od.ctrl[:] = u32[e]
         Ao, Bo = od.transition_fd(eps, True)
         worst = max(worst, np.abs(A[e] - Ao).max() / max(1.0, np.abs(Ao).max()), np.abs(Bm[e] - Bo).max() / max(1.0, np.abs(Bo).max()))
-    assert worst < 5e-5, worst
+    measured(f"transition_fd/{name}/B{B}", worst, FD_TOL[name], "(relative to the largest entry of A / B)")
     assert A.shape == (B, 2 * cm.nv, 2 * cm.nv) and Bm.shape == (B, 2 * cm.nv, cm.nu)
     assert np.array_equal(sim.get("qpos"), q32)              # state untouched
 
@@ -375,6 +404,43 @@ def test_transition_fd_respects_ctrlrange(world):
     Ao, Bo = od.transition_fd(1e-6, True)
     assert np.abs(Bm[1] - Bo).max() < 1e-5 * max(1.0, np.abs(Bo).max())
     assert np.abs(Bm[1]).max() > 0
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_transition_fd_humanoid_in_contact_matches_oracle(world, dtype):
+    """The (A, B) the reference's LQR example consumes (reference examples/humanoid/controllers/lqr.py:90 ->
+    mujoco_template/linearization.py:16-35): mjd_transitionFD, eps 1e-6 centred, at the ``stand_on_left_leg`` keyframe - one foot
+    on the floor, contacts and joint limits active - and at standing states reached by short random-ctrl rollouts from qpos0 (both
+    feet down, a non-trivial solver warm start in ``qacc_warmstart``).  Device float64 FD vs the oracle's FD about the same state;
+    every column starts from the SAME saved warm start on both sides (oracle RESTORE(), k_fd reloads it), which the comparison of
+    the contact-dominated velocity rows would expose; the state and the warm start are untouched afterwards."""
+    cm, om, dm = world("humanoid")
+    key = cm.name2id(mjcf.OBJ_KEY, "stand_on_left_leg")
+    B = 6
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    ods[0].reset_keyframe(key)                                # exactly the example's set-point (qvel 0, key ctrl)
+    ods[1].reset_keyframe(key); ods[1].rollout_random(8, seed=3, env=1, scale=0.2)      # the keyframe, settled into its contacts a few steps
+    for e in range(2, B):
+        ods[e].rollout_random(10 + 4 * e, seed=3, env=e, scale=0.3)                  # standing on both feet, warm start from the trajectory
+    state = {k: np.stack([getattr(od, k) for od in ods]) for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+    sim = BatchSim(dm, B, dtype=dtype)
+    for k, v in state.items():
+        sim.set(k, v)
+    dev = {k: sim.get(k) for k in state}                     # what the device holds (fp32: the rounded state both sides linearise about)
+    A, Bm = sim.transition_fd(1e-6, True)
+    worst, ncon = 0.0, []
+    for e, od in enumerate(ods):
+        for k in state:
+            getattr(od, k)[:] = dev[k][e]
+        od.forward()
+        ncon.append(od.counters()["ncon"])
+        od.qacc_warmstart[:] = dev["qacc_warmstart"][e]
+        Ao, Bo = od.transition_fd(1e-6, True)
+        worst = max(worst, np.abs(A[e] - Ao).max() / max(1.0, np.abs(Ao).max()), np.abs(Bm[e] - Bo).max() / max(1.0, np.abs(Bo).max()))
+    assert min(ncon) >= 1, ncon                              # every state is IN contact
+    measured(f"transition_fd_in_contact/humanoid/{dtype}", worst, FD_CONTACT_TOL[dtype], f"(relative; contacts per state {ncon})")
+    for k in state:
+        assert np.array_equal(sim.get(k), dev[k]), k         # linearising leaves the state and the warm start alone
 
 
 def test_jacobians_match_oracle(world):
@@ -466,14 +532,19 @@ def test_device_feedback_controller_matches_host_law(world):
                 od.ctrl[:] = np.clip(u0 - K @ np.concatenate([dq, od.qvel - v0]), lo, hi)
                 od.step()
         ref = np.stack([od.qpos for od in ods])
-        for dtype, tol in (("float64", 1e-9), ("float32", 5e-4)):
+        for dtype, tol in (("float64", 1e-9), ("float32", FB_TOL32[name][0])):
             sim = BatchSim(dm, B, dtype=dtype)
             sim.set("qpos", q); sim.set("qvel", v)
             sim.set_feedback(K, u0, q0, v0)
             from mujoco_template_amd._capi import CTRL_FEEDBACK
             sim.rollout(T, CTRL_FEEDBACK)
-            assert np.abs(sim.get("qpos") - ref).max() <= tol, (name, dtype)
-            assert np.abs(sim.get("ctrl") - np.stack([od.ctrl for od in ods])).max() <= (1e-8 if dtype == "float64" else 5e-3)
+            eq = np.abs(sim.get("qpos") - ref).max()
+            eu = np.abs(sim.get("ctrl") - np.stack([od.ctrl for od in ods])).max()
+            if dtype == "float64":
+                assert eq <= tol and eu <= 1e-8, (name, dtype, eq, eu)
+            else:
+                measured(f"device_feedback/{name}/qpos_fp32", eq, tol)
+                measured(f"device_feedback/{name}/ctrl_fp32", eu, FB_TOL32[name][1])
     with pytest.raises(mt.ConfigError):
         BatchSim(world("cartpole")[2], 2).rollout(1, 3)          # feedback mode without gains
 
@@ -531,12 +602,98 @@ def test_config5_drone_contacts_flat_observation_gather_full_size(world):
     assert ring[-1][:, 0:3] == pytest.approx(xpos[:, bid], abs=1e-6)
     sid = [cm.name2id(mjcf.OBJ_SITE, n) for n in ("imu", "thrust1", "thrust2", "thrust3", "thrust4")]
     assert ring[-1][:, 16:31].reshape(B, 5, 3) == pytest.approx(site[:, sid], abs=1e-6)
-    # oracle on a sample (hovering half: no contact, smooth): fp32 drift <= 1e-4 over 100 steps
+    # oracle on a sample (hovering half: no contact, smooth): fp32 drift over 100 steps
+    worst = 0.0
     for e in (0, 7, 1023):
         od = mjo.OracleData(om)
         od.qpos[:] = q0[e]
         od.rollout_random(100, seed=5, env=e, scale=0.3)
-        assert np.abs(ring[99][e, 3:10] - od.qpos).max() < 1e-4, e
+        worst = max(worst, np.abs(ring[99][e, 3:10] - od.qpos).max())
+    measured("config5/hover_half/fp32_drift_100_steps", worst, CFG5_TOL["hover100"])
+    # ... and the DROPPED half against the oracle.  Under this controller (ctrl in [4.55, 8.45] per rotor, hover needs 3.25) a dropped
+    # drone lifts off at once; the contacts of this workload are the drones that tumble under the unequal thrusts and come down
+    # again (first contacts from step ~140 on).  The sample = dropped environments that are ON the floor at the end of the run.
+    on_floor = np.nonzero(cn["ncon"][B // 2:] > 0)[0] + B // 2
+    assert on_floor.size >= 4
+    sample = [int(e) for e in on_floor[:4]]
+    wq = wv = 0.0
+    for e in sample:
+        od = mjo.OracleData(om)
+        od.qpos[:] = q0[e]
+        first = None
+        hist = []                                               # (qpos, qvel, warm start) before every step
+        for s in range(T):
+            hist.append((np.array(od.qpos), np.array(od.qvel), np.array(od.qacc_warmstart)))
+            od.ctrl[:] = od.random_ctrl(5, e, s, 0.3); od.step()
+            if first is None and od.counters()["ncon"] > 0:
+                first = s
+        assert first is not None and od.counters()["ncon"] > 0
+        #  (i) float64 kernels free-running through the tumble and the landing (env0 keys the random stream: one environment per object)
+        s1 = BatchSim(dm, 1, dtype="float64", env0=e)
+        s1.set("qpos", q0[e:e + 1])
+        s1.rollout(T, CTRL_RANDOM, seed=5, ctrl_scale=0.3)
+        assert np.abs(s1.get("qpos")[0] - od.qpos).max() < 1e-8, e
+        assert s1.counters()["ncon"][0] == od.counters()["ncon"]
+        # (ii) fp32 teacher-forced single steps along the oracle's trajectory from 5 steps before the first contact to the end
+        s32 = BatchSim(dm, 1, dtype="float32", env0=e)
+        od2 = mjo.OracleData(om)
+        for s in range(max(0, first - 5), T):
+            qh, vh, wh = hist[s]
+            od2.qpos[:] = qh; od2.qvel[:] = vh; od2.qacc_warmstart[:] = wh
+            od2.ctrl[:] = od2.random_ctrl(5, e, s, 0.3)
+            s32.set("qpos", qh[None]); s32.set("qvel", vh[None]); s32.set("qacc_warmstart", wh[None]); s32.set("ctrl", np.array(od2.ctrl)[None])
+            s32.step(1)
+            od2.step()
+            wq = max(wq, np.abs(s32.get("qpos")[0] - od2.qpos).max())
+            wv = max(wv, (np.abs(s32.get("qvel")[0] - od2.qvel) / np.maximum(1.0, np.abs(od2.qvel))).max())
+    measured("config5/crashed_drones/teacher_forced_qpos", wq, CFG5_TOL["tf_q"])
+    measured("config5/crashed_drones/teacher_forced_qvel_rel", wv, CFG5_TOL["tf_v"])
+
+
+def test_config5_drones_landing_on_the_floor_match_the_oracle(world):
+    """The contact half of config 5 as SURVEY §8(d) meant it (drones that come to rest ON the floor): 64 drones dropped from z = 0.1
+    with random tilts and spins under zero thrust; they land on their feet / edges (1 - 4 box-corner contacts with pyramidal friction).  float64 kernels free-running vs the oracle over the whole landing (rounding level),
+    fp32 teacher-forced single steps along the oracle's trajectory, and the flat observation of config 5 gathered through it."""
+    import mujoco_template_amd as mt
+
+    cm, om, dm = world("drone2")
+    B, T = 64, 150
+    rng = np.random.default_rng(17)
+    od0 = mjo.OracleData(om)
+    key_qpos = np.array(cm.arrays["key_qpos"]).reshape(-1, cm.nq)[0].copy(); key_qpos[2] = 0.1
+    q0 = np.stack([od0.integrate_pos(key_qpos, np.concatenate([np.zeros(3), rng.normal(size=3) * 0.3]), 1.0) for _ in range(B)])
+    v0 = np.concatenate([rng.normal(size=(B, 3)) * 0.2, rng.normal(size=(B, 3)) * 1.0], axis=1)
+    ods = []
+    for e in range(B):
+        od = mjo.OracleData(om); od.qpos[:] = q0[e]; od.qvel[:] = v0[e]; ods.append(od)
+    sim64, sim32 = BatchSim(dm, B, dtype="float64"), BatchSim(dm, B, dtype="float32")
+    sim64.set("qpos", q0); sim64.set("qvel", v0)
+    wq = wv = 0.0
+    peak_con = 0
+    for s in range(T):
+        for k in ("qpos", "qvel", "qacc_warmstart"):
+            sim32.set(k, np.stack([getattr(od, k) for od in ods]))
+        sim32.step(1)                                          # ctrl stays zero
+        for od in ods:
+            od.step()
+        peak_con = max(peak_con, max(od.counters()["ncon"] for od in ods))
+        qo, vo = np.stack([od.qpos for od in ods]), np.stack([od.qvel for od in ods])
+        wq = max(wq, np.abs(sim32.get("qpos") - qo).max())
+        wv = max(wv, (np.abs(sim32.get("qvel") - vo) / np.maximum(1.0, np.abs(vo))).max())
+    sim64.rollout(T, CTRL_ZERO)
+    assert np.abs(sim64.get("qpos") - np.stack([od.qpos for od in ods])).max() < 1e-9
+    c64 = sim64.counters()
+    assert c64["ncon"].tolist() == [od.counters()["ncon"] for od in ods] and c64["con_dropped"].sum() == 0 and c64["efc_dropped"].sum() == 0
+    assert peak_con >= 4 and min(od.counters()["ncon"] for od in ods) >= 1        # everyone is lying on the floor (flat: its four feet)
+    measured("config5/landing/teacher_forced_qpos", wq, CFG5_TOL["land_q"])
+    measured("config5/landing/teacher_forced_qvel_rel", wv, CFG5_TOL["land_v"])
+    # the flat observation of config 5 through the landing (Env API, ZeroController): last ring row == state arrays
+    spec = mt.ObservationSpec(sites_pos=("imu", "thrust1", "thrust2", "thrust3", "thrust4"), bodies_pos=("x2",), as_dict=False)
+    env = mt.Env.from_xml_path(MODELS["drone2"], obs_spec=spec, controller=mt.ZeroController(), batch=B)
+    env.data.qpos[...] = q0; env.data.qvel[...] = v0
+    ring = env.rollout(T, obs_every=1).cpu().numpy()
+    assert ring.shape == (T, B, 31)
+    measured("config5/landing/fp32_free_running_qpos_150_steps", np.median(np.abs(ring[-1][:, 3:10] - np.stack([od.qpos for od in ods])).max(axis=1)), CFG5_TOL["land_free_median"])
 
 
 @pytest.mark.parametrize("name", ["humanoid", "drone2", "cartpole", "pendulum"])
@@ -632,6 +789,50 @@ def test_ticket_schedule_many_hand_overs(world, monkeypatch):
         res[mode] = [sim.get(k) for k in ("qpos", "qvel", "qacc_warmstart", "time")]
     for a, b in zip(res["static"], res["tickets"]):
         assert np.array_equal(a, b)
+
+
+def test_hand_over_time_out_stops_the_environment_and_crosses_the_abi(world, monkeypatch):
+    """The give-up path of the ticket map, forced: the hand-overs of ONE environment are published with a wrong tag (test hook
+    MJB_XFER_POISON_ENV) and the wait is bounded at 3 ms of wall clock (MJB_XFER_TIMEOUT_MS).  The wave that draws that environment's
+    second chunk gives up: it raises engine flag 8, marks the environment dead for the later chunks and does NOT step it.  Checked
+    through the C ABI: the launch call itself returns OK (nothing synchronises), the next synchronising call and every further launch
+    return MJB_ERR_DEVICE (TemplateError), ``mjb_engine_flags`` reports bit 3, the dead environment's arrays hold the state the launch
+    started from, every other environment is bitwise where the static map puts it, and ``mjb_reset`` clears the condition."""
+    import mujoco_template_amd as mt
+
+    cm, om, dm = world("humanoid")
+    B, T, victim = 2048 + 512, 12, 1234          # more blocks than resident slots is not needed: the chunk length is forced
+    monkeypatch.setenv("MJB_CHUNK_STEPS", "0")
+    ref = BatchSim(dm, B, dtype="float32")
+    ref.rollout(T, CTRL_RANDOM, seed=2)
+    q_ref, q_start = ref.get("qpos"), BatchSim(dm, B, dtype="float32").get("qpos")
+    monkeypatch.setenv("MJB_CHUNK_STEPS", "3")
+    monkeypatch.setenv("MJB_XFER_POISON_ENV", str(victim))
+    monkeypatch.setenv("MJB_XFER_TIMEOUT_MS", "3")
+    sim = BatchSim(dm, B, dtype="float32")
+    assert sim.engine_flags() == 0
+    sim.rollout(T, CTRL_RANDOM, seed=2)                        # returns OK: the failure is not known yet
+    assert sim.schedule_info()["map"] == "tickets"
+    with pytest.raises(mt.TemplateError, match="hand-over"):
+        sim.sync()
+    assert sim.engine_flags() & 8
+    with pytest.raises(mt.TemplateError):
+        sim.rollout(1, CTRL_RANDOM, seed=2, step0=T)           # no launch on top of a failed one
+    with pytest.raises(mt.TemplateError):
+        sim.get("qpos")
+    # what the arrays hold (read through the raw device pointer: the getters refuse)
+    import torch
+    q = sim.torch_view("qpos").cpu().numpy().astype(np.float64)
+    others = np.arange(B) != victim
+    assert np.array_equal(q[others], q_ref[others])            # everyone else finished the launch, bit for bit
+    assert np.array_equal(q[victim], q_start[victim])          # the dead environment was not advanced, and nothing torn was stored
+    sim.reset()
+    assert sim.engine_flags() == 0
+    monkeypatch.delenv("MJB_XFER_POISON_ENV")
+    ok = BatchSim(dm, B, dtype="float32")                      # the same launch without the poison: completes and equals the static map
+    ok.rollout(T, CTRL_RANDOM, seed=2)
+    ok.sync()
+    assert np.array_equal(ok.get("qpos"), q_ref) and ok.engine_flags() & 8 == 0
 
 
 @pytest.mark.parametrize("name,B", [("humanoid", 24), ("cartpole", 512), ("drone2", 64)])

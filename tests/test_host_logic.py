@@ -292,6 +292,46 @@ def test_binary_model_round_trip_and_names_through_the_c_abi(tmp_path):
         mj.MjModel.from_binary_path(str(bad))
 
 
+def test_binary_model_keeps_edited_options_and_rejects_a_crafted_count(tmp_path):
+    """Like mj_saveModel the file carries the options as they are when it is written (disableactuator / iterations / tolerance edited
+    after compilation), and a crafted int64 element count must be refused instead of wrapping the byte size."""
+    import struct
+
+    model = mj.MjModel.from_xml_path(os.path.join(ROOT, "models", "cartpole.xml"))
+    model.opt.iterations = 7
+    model.opt.tolerance = 3e-5
+    model.opt.disableactuator = 2
+    path = str(tmp_path / "cp.mjbm")
+    mj.mj_saveModel(model, path, None)
+    again = mj.MjModel.from_binary_path(path)
+    assert (again.opt.iterations, again.opt.tolerance, again.opt.disableactuator) == (7, 3e-5, 2)
+    # corrupt the count of the first field: 2^61 elements of 8 bytes wraps to 0 bytes in size_t arithmetic
+    raw = bytearray(open(path, "rb").read())
+    nl = struct.unpack_from("<i", raw, 12)[0]
+    off = 12 + 4 + nl + 4                                      # magic(8) nfield(4) | namelen(4) name dtype(4) count(8)
+    for evil in (1 << 61, (1 << 62) + 1, (1 << 63) - 1):
+        struct.pack_into("<q", raw, off, evil)
+        bad = tmp_path / "evil.mjbm"
+        bad.write_bytes(bytes(raw))
+        with pytest.raises(ValueError, match="truncated|corrupt"):
+            mj.MjModel.from_binary_path(str(bad))
+
+
+def test_include_cycles_raise_instead_of_overflowing_the_stack(tmp_path):
+    """A self-including file, a two-file cycle and a file included twice are rejected with the compiler's error (MuJoCo rejects
+    repeated includes); before, the recursion ran until the process segfaulted."""
+    (tmp_path / "self.xml").write_text('<mujoco><include file="self.xml"/><worldbody/></mujoco>')
+    (tmp_path / "a.xml").write_text('<mujoco><include file="b.xml"/><worldbody/></mujoco>')
+    (tmp_path / "b.xml").write_text('<mujoco><include file="a.xml"/></mujoco>')
+    (tmp_path / "part.xml").write_text('<mujoco><worldbody><body><geom size="0.1"/><joint/></body></worldbody></mujoco>')
+    (tmp_path / "twice.xml").write_text('<mujoco><include file="part.xml"/><include file="part.xml"/></mujoco>')
+    (tmp_path / "once.xml").write_text('<mujoco><include file="part.xml"/></mujoco>')
+    for name in ("self.xml", "a.xml", "twice.xml"):
+        with pytest.raises(ValueError, match="more than once|cycle"):
+            mj.MjModel.from_xml_path(str(tmp_path / name))
+    assert mj.MjModel.from_xml_path(str(tmp_path / "once.xml")).nv == 1
+
+
 def test_module_smoke_cli_fails_loudly_without_a_gpu():
     """No CPU fallback anywhere, the smoke CLI included: without a HIP device it exits non-zero and names the reason."""
     import torch
