@@ -822,6 +822,8 @@ static StepArgs make_args(mjbData* d, int nstep, int ctrl_mode, unsigned seed, u
   std::memset(&a, 0, sizeof(a));
   a.nstep = nstep; a.ctrl_mode = ctrl_mode; a.seed = seed; a.step0 = step0; a.env0 = (unsigned)d->env0;
   a.ctrl_scale = scale; a.dt = d->model->h.timestep; a.mode = mode; a.write_kin = 1; a.obs_every = 0;
+  static const int rep = std::getenv("MJB_REPEAT_PHASE") ? std::atoi(std::getenv("MJB_REPEAT_PHASE")) : -1;   // diagnostic kernels only (-DMJB_PHASE_REPEAT)
+  a.repeat_phase = rep;
   return a;
 }
 

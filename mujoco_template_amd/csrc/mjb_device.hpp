@@ -538,6 +538,9 @@ template <typename T> struct Ctx {
   int* wi;   // int region
   int lane;
   int ncon, nefc, niter, con_dropped, efc_dropped;
+#if defined(MJB_PHASE_REPEAT) && !defined(MJB_HOST_EMU)
+  int rep = -1;                 // index (PH_*) of the phase that runs twice (diagnostic build)
+#endif
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   unsigned long long pacc[PH_N] = {};
   unsigned long long pt = 0;
@@ -2228,20 +2231,29 @@ template <typename T, typename TS, int G> MJB_DEV void sensors(const Ctx<T>& c, 
 // ---------------------------------------------------------------------------
 // The three stages of mj_forward, separately callable: mjd_transitionFD skips the stages a perturbed column cannot change
 // (MuJoCo's mj_stepSkip: ctrl columns keep the position and velocity stages, velocity columns the position stage).
+// Diagnostic build -DMJB_PHASE_REPEAT (scripts/gpu_phase_pmc.py): the phase whose index equals StepArgs::repeat_phase runs TWICE.
+// Every phase wrapped below recomputes its outputs from LDS inputs it does not modify (idempotent), so the state evolves exactly
+// as in the product kernel and the DIFFERENCE of the hardware counters of two passes (repeat k vs no repeat) is phase k's own
+// instruction count, active-lane cycles and executed flops.  The product build compiles the plain call.
+#if defined(MJB_PHASE_REPEAT) && !defined(MJB_HOST_EMU)
+#define MJB_PHASE_CALL(c, k, call) do { call; if ((c).rep == (k)) { gsync<G>(); call; } } while (0)
+#else
+#define MJB_PHASE_CALL(c, k, call) do { call; } while (0)
+#endif
 template <typename T, int G> MJB_DEV void forward_position(Ctx<T>& c) {
   MJB_STAMP(c, PH_OTHER);
-  kinematics<T, G>(c); MJB_STAMP(c, PH_KIN);
-  com_pos<T, G>(c); MJB_STAMP(c, PH_COM);
-  collision<T, G>(c); MJB_STAMP(c, PH_COLL);
-  crb_factor<T, G>(c); MJB_STAMP(c, PH_CRB);
+  MJB_PHASE_CALL(c, PH_KIN, (kinematics<T, G>(c))); MJB_STAMP(c, PH_KIN);
+  MJB_PHASE_CALL(c, PH_COM, (com_pos<T, G>(c))); MJB_STAMP(c, PH_COM);
+  MJB_PHASE_CALL(c, PH_COLL, (collision<T, G>(c))); MJB_STAMP(c, PH_COLL);
+  MJB_PHASE_CALL(c, PH_CRB, (crb_factor<T, G>(c))); MJB_STAMP(c, PH_CRB);
 }
 // constraint rows (their reference acceleration depends on qvel) + bias / passive forces
 template <typename T, int G> MJB_DEV void forward_velocity(Ctx<T>& c) {
-  make_constraint<T, G>(c); MJB_STAMP(c, PH_CONS);
-  vel_bias_passive<T, G>(c); MJB_STAMP(c, PH_VEL);
+  MJB_PHASE_CALL(c, PH_CONS, (make_constraint<T, G>(c))); MJB_STAMP(c, PH_CONS);
+  MJB_PHASE_CALL(c, PH_VEL, (vel_bias_passive<T, G>(c))); MJB_STAMP(c, PH_VEL);
 }
 template <typename T, int G> MJB_DEV void forward_acceleration(Ctx<T>& c) {
-  actuation_acceleration<T, G>(c); MJB_STAMP(c, PH_ACT);
+  MJB_PHASE_CALL(c, PH_ACT, (actuation_acceleration<T, G>(c))); MJB_STAMP(c, PH_ACT);
   solve_constraints<T, G>(c); MJB_STAMP(c, PH_SOLVE);
   if (c.mp->nsensor > 0) { sensors<T, T, G>(c, c.w + c.lp->sens); gsync<G>(); }   // like mj_forward: sensors see the pre-integration state
 }
@@ -2273,6 +2285,14 @@ template <typename T, int G> MJB_DEV void euler(Ctx<T>& c, const mjb_f16v* inv =
   T h = m.timestep;
   if (m.has_damping) {
     T *qs = w + L.qfrc_smooth, *qc = w + L.qfrc_constraint;
+#if defined(MJB_PHASE_REPEAT) && !defined(MJB_HOST_EMU)
+    if (c.rep == PH_INTEG) {                                   // the implicit-damping solve twice (right-hand side rebuilt: idempotent)
+      for (int i = lane; i < nv; i += G) tmpv[i] = qs[i] + qc[i];
+      gsync<G>();
+      factor_W<T, G>(c, 2, tmpv);
+      gsync<G>();
+    }
+#endif
     for (int i = lane; i < nv; i += G) tmpv[i] = qs[i] + qc[i];
     gsync<G>();
 #ifndef MJB_HOST_EMU
@@ -2596,6 +2616,9 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
 #endif
   if (a.mode != 0) { s_begin = 0; s_end = 1; }
   c.skip_dynamics = a.mode == 2;
+#if defined(MJB_PHASE_REPEAT) && !defined(MJB_HOST_EMU)
+  c.rep = a.mode == 0 ? a.repeat_phase : -1;
+#endif
   const int nstage = (a.mode == 0 && m.integrator == INT_RK4) ? 4 : 1;
 #ifndef MJB_HOST_EMU
   const unsigned hwslot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_ID[3:0]: this wave's slot on its SIMD

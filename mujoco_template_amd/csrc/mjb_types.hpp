@@ -161,6 +161,8 @@ struct StepArgs {
   unsigned tagbase;      // ticket mode: tag of this launch's hand-overs (+ the step index at which the hand-over happens), unique among the launches that could still be in the buffer
   int nblk, grid_blocks; // ticket mode: environment blocks of the batch; workgroups launched (the resident ones)
   int chunk_steps;       // >0: TICKET mode of k_step - workgroups draw (environment block, chunk of steps) tickets from d.sched (mjb_kernels.hpp)
+  int repeat_phase;      // diagnostic builds only (-DMJB_PHASE_REPEAT, scripts/gpu_phase_pmc.py): the idempotent phase with this index runs TWICE per
+                         // step, so that the difference of two PMC passes is that phase's instruction / lane / flop count; -1 / product build: ignored
   unsigned xfer_timeout; // ticket mode: how long a wave waits for a hand-over before it gives up, in ticks of the 100 MHz wall clock (s_memrealtime)
   int xfer_poison_env;   // test hook (MJB_XFER_POISON_ENV): the hand-overs of environment (this - 1) are published with a wrong tag; 0 = off
   int nuniform, nchunk;  // ticket mode, the chunk plan of an environment's nstep steps: `nuniform` chunks of chunk_steps steps, then every

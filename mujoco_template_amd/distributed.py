@@ -7,7 +7,9 @@ environment index (``env0``), so results do not depend on the number of GPUs.
 
 from __future__ import annotations
 
+import ctypes
 import os
+from dataclasses import dataclass
 
 
 def world() -> tuple[int, int, int]:
@@ -86,4 +88,114 @@ def all_gather_obs(local_obs, global_batch: int | None = None, counts=None, sing
     return out.to(home).movedim(0, -2)
 
 
-__all__ = ["world", "shard_range", "init_process_group", "all_gather_obs"]
+@dataclass(frozen=True)
+class ShardPlan:
+    """Which contiguous block of a GLOBAL batch this process owns: what ``Env.from_xml_path(..., batch=GLOBAL,
+    shard=True)`` derives from the torchrun environment and keeps as ``env.shard``.  ``gather`` is the path's one collective."""
+
+    rank: int
+    world_size: int
+    local_rank: int
+    global_batch: int
+    env0: int
+    count: int
+    counts: tuple
+
+    @classmethod
+    def from_environment(cls, global_batch: int, rank: int | None = None, world_size: int | None = None, local_rank: int | None = None) -> "ShardPlan":
+        r, ws, lr = world()
+        rank = r if rank is None else int(rank)
+        world_size = ws if world_size is None else int(world_size)
+        local_rank = lr if local_rank is None else int(local_rank)
+        if int(global_batch) < world_size:
+            raise ValueError(f"global batch {global_batch} is smaller than the number of ranks {world_size}")
+        env0, count = shard_range(global_batch, rank, world_size)
+        counts = tuple(shard_range(global_batch, k, world_size)[1] for k in range(world_size))
+        return cls(rank, world_size, local_rank, int(global_batch), env0, count, counts)
+
+    @property
+    def equal_shards(self) -> bool:
+        return len(set(self.counts)) == 1
+
+    def gather(self, local_obs, comm: "RcclCommunicator | None" = None, stream=None):
+        """``[..., count, dim]`` of this rank -> ``[..., global_batch, dim]`` on every rank (rank order = environment order).  With an
+        ``RcclCommunicator`` and equal shards the collective is the library's own C-ABI entry point ``mjb_allgather_obs``
+        (ncclAllGather on the given HIP stream); otherwise ``torch.distributed`` (``all_gather_obs``)."""
+        if self.world_size == 1 and comm is None:
+            return local_obs
+        if comm is not None and self.equal_shards and getattr(local_obs, "is_cuda", False):
+            return comm.all_gather_obs(local_obs, stream=stream)
+        return all_gather_obs(local_obs, counts=list(self.counts))
+
+
+class _NcclUniqueId(ctypes.Structure):                             # ncclUniqueId: 128 opaque bytes, passed BY VALUE
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+class RcclCommunicator:
+    """An ``ncclComm_t`` of this process' own, so that the observation all-gather runs through the library's C-ABI collective
+    (``mjb_allgather_obs`` -> ``ncclAllGather``, include/mjbatch.h) instead of ``torch.distributed``: the unique id is made on rank 0,
+    carried to the other ranks over the already initialised ``torch.distributed`` group (any backend), and every rank calls
+    ``ncclCommInitRank`` on the RCCL that torch loaded.  One rank per GPU (RCCL refuses two ranks on one device)."""
+
+    def __init__(self, rank: int, world_size: int, device: int):
+        import torch
+        import torch.distributed as dist
+
+        self._rccl = None
+        for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"):
+            try:
+                self._rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+        if self._rccl is None:
+            raise RuntimeError("no loadable librccl")
+        R = self._rccl
+        R.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+        R.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        R.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        uid = _NcclUniqueId()
+        if rank == 0 and R.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if world_size > 1:
+            box = [bytes(uid.internal) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        torch.cuda.set_device(device)
+        self.comm = ctypes.c_void_p()
+        rc = R.ncclCommInitRank(ctypes.byref(self.comm), int(world_size), uid, int(rank))
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed with ncclResult {rc}")
+        self.rank, self.world_size, self.device = int(rank), int(world_size), int(device)
+
+    def all_gather_obs(self, local_obs, stream=None):
+        """``[..., b, dim]`` -> ``[..., world_size * b, dim]`` (equal shards) through ``mjb_allgather_obs`` on ``stream`` (default: torch's current)."""
+        import torch
+
+        from ._capi import _check, load_library
+
+        L = load_library()
+        L.mjb_allgather_obs.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p]
+        L.mjb_allgather_obs.restype = ctypes.c_int
+        x = local_obs.movedim(-2, 0).contiguous()                  # [b, ..., dim]: rank blocks are contiguous along the batch axis
+        out = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        dtype = {torch.float32: 0, torch.float64: 1}[x.dtype]
+        _check(L.mjb_allgather_obs(self.comm, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), x.numel(), dtype, ctypes.c_void_p(stream)))
+        return out.movedim(0, -2)
+
+    def close(self) -> None:
+        if getattr(self, "comm", None) and self._rccl is not None:
+            self._rccl.ncclCommDestroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["world", "shard_range", "init_process_group", "all_gather_obs", "ShardPlan", "RcclCommunicator"]

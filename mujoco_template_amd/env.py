@@ -9,6 +9,11 @@ a key the environment produced (``TemplateError``).
 What the batched engine adds:
 
 * ``from_xml_path(..., batch, dtype, device, lanes, nconmax, nefcmax, env0, specialize)``;
+* ``from_xml_path(..., batch=GLOBAL, shard=True)``: one process per GPU (torchrun environment) - this process takes its contiguous
+  block of the global batch (``env.shard``: a ``distributed.ShardPlan``), keys its random streams by the GLOBAL environment index
+  and steps it on ``cuda:LOCAL_RANK``; ``rollout(..., gather=True)`` / ``gather_observations`` return the observation block of the
+  WHOLE batch on every rank (the path's one collective: RCCL all-gather, through the library's ``mjb_allgather_obs`` when this
+  process can own an ``ncclComm_t``);
 * two ways through a step.  *Host-driven*: any Python controller, one engine call per sub-step (``_advance_on_host``).
   *Fused*: a controller whose law the step kernel can evaluate itself (``control.device_ctrl_mode_of``) runs inside ONE
   kernel launch for all sub-steps (``rollout``); ``step`` picks it automatically;
@@ -69,6 +74,10 @@ class Env:
         self._warnings_reported = False
         self._engine_warnings_reported = 0
         self._compat_warnings: list[str] = []
+        self.shard = None                 # distributed.ShardPlan when created with shard=True
+        self._collective = "auto"
+        self._comm = None                 # RcclCommunicator (lazily, first gather)
+        self.gather_collective = None     # which collective the last gather used (reported by bench.py)
         self._select_actuator_groups(enabled_groups)
         if controller is not None:
             controller.prepare(self.model, self.data)
@@ -100,17 +109,37 @@ class Env:
     def from_xml_path(cls, xml_path: str, *, obs_spec: ObservationSpec | None = None, controller: Controller | None = None,
                       reward_fn=None, done_fn=None, info_fn=None, enabled_groups: Iterable[int] | None = None,
                       control_decimation: int = 1, auto_reset: bool = True, keyframe: int | str | None = None,
-                      batch: int = 1, dtype: str = "float32", device: int = 0, lanes: int = 0, nconmax: int = 0,
-                      nefcmax: int = 0, env0: int = 0, specialize: bool | None = None) -> "Env":
+                      batch: int = 1, dtype: str = "float32", device: int | None = None, lanes: int = 0, nconmax: int = 0,
+                      nefcmax: int = 0, env0: int = 0, specialize: bool | None = None, shard: bool = False,
+                      collective: str = "auto") -> "Env":
+        """Reference signature (``mujoco_template/env.py:100-143``) + the engine's keywords.  ``shard=True``: ``batch`` is the GLOBAL batch
+        of a one-process-per-GPU job (RANK / WORLD_SIZE / LOCAL_RANK from the torchrun environment); this process creates its
+        contiguous block on ``cuda:LOCAL_RANK`` (``device`` overrides) with ``env0`` = the block's first global index.
+        ``collective``: ``"auto"`` (the library's ``mjb_allgather_obs`` on an own RCCL communicator when the process group's backend is
+        ``nccl`` and the shards are equal, else ``torch.distributed``), ``"rccl"`` (require the former), ``"torch"``."""
         if keyframe is not None and not auto_reset:
             raise ConfigError("auto_reset=False is incompatible with specifying a keyframe")
-        handle = ModelHandle.from_xml_path(xml_path, batch=batch, dtype=dtype, device=device, lanes=lanes, nconmax=nconmax,
+        if collective not in ("auto", "rccl", "torch"):
+            raise ConfigError("collective must be 'auto', 'rccl' or 'torch'")
+        plan = None
+        if shard:
+            from .distributed import ShardPlan
+
+            try:
+                plan = ShardPlan.from_environment(batch)
+            except ValueError as exc:
+                raise ConfigError(str(exc)) from None
+            batch, env0 = plan.count, int(env0) + plan.env0
+            if device is None:
+                device = plan.local_rank if plan.world_size > 1 else 0
+        handle = ModelHandle.from_xml_path(xml_path, batch=batch, dtype=dtype, device=0 if device is None else device, lanes=lanes, nconmax=nconmax,
                                            nefcmax=nefcmax, env0=env0, specialize=specialize)
         if controller is not None and hasattr(controller, "env0"):
             controller.env0 = env0                  # device-side RNG streams are keyed by the GLOBAL environment index
         env = cls(handle, obs_spec=obs_spec if obs_spec is not None else ObservationSpec(include_sensordata=False),
                   controller=controller, reward_fn=reward_fn, done_fn=done_fn, info_fn=info_fn,
                   enabled_groups=enabled_groups, control_decimation=control_decimation)
+        env.shard, env._collective = plan, collective
         if auto_reset:
             env.reset(keyframe)
         return env
@@ -149,12 +178,67 @@ class Env:
             return False
         return not (self.extractor is not None and self.extractor.extra_items)
 
-    def rollout(self, nsteps: int, *, obs_every: int = 0, obs_out=None, obs_spec_handle=None):
+    # -- multi-GPU: the one collective of the path --------------------------------------------------
+    def _communicator(self):
+        """The process' own RCCL communicator for ``mjb_allgather_obs`` (created at the first gather), or ``None`` = use torch.distributed."""
+        if self._collective == "torch" or self.shard is None:
+            return None
+        if self._comm is not None:
+            return self._comm or None
+        import torch.distributed as dist
+
+        usable = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and self.shard.equal_shards
+        if not usable:
+            if self._collective == "rccl":
+                raise ConfigError("collective='rccl' needs an initialised torch.distributed group with backend 'nccl' and equal shards")
+            self._comm = False
+            return None
+        from .distributed import RcclCommunicator
+
+        try:
+            self._comm = RcclCommunicator(self.shard.rank, self.shard.world_size, self.data.sim.device)
+        except Exception as exc:                                   # no loadable RCCL / init refused: the torch collective still works
+            if self._collective == "rccl":
+                raise TemplateError(f"could not create an RCCL communicator: {exc}") from exc
+            warnings.warn(f"mjb_allgather_obs unavailable ({exc}); the observation all-gather uses torch.distributed", RuntimeWarning)
+            self._comm = False
+            return None
+        return self._comm
+
+    def gather_observations(self, local_obs):
+        """All-gather a device observation block ``[..., local batch, dim]`` of a sharded environment into ``[..., GLOBAL batch, dim]`` on
+        every rank (environment order).  Without ``shard=True`` (or in a one-process job without a process group) it is the identity."""
+        if self.shard is None:
+            return local_obs
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            if self.shard.world_size > 1:
+                raise ConfigError("a sharded Env needs torch.distributed initialised before gathering (distributed.init_process_group())")
+            self.gather_collective = "identity (one process, no process group)"
+            return local_obs
+        comm = self._communicator()
+        if comm is not None:
+            self.gather_collective = "mjb_allgather_obs (ncclAllGather on the library's own RCCL communicator)"
+            return self.shard.gather(local_obs, comm=comm, stream=None)
+        self.gather_collective = f"torch.distributed ({dist.get_backend()})"
+        from .distributed import all_gather_obs
+
+        return all_gather_obs(local_obs, counts=list(self.shard.counts), single_rank=True)
+
+    def observe_device(self, gather: bool = False):
+        """Flat observation ``[batch, obs_dim]`` of the current state as a torch tensor on the GPU (``ObservationExtractor.gather_device``);
+        ``gather=True`` on a sharded environment: the all-gathered ``[GLOBAL batch, obs_dim]``."""
+        obs = self._ensure_extractor().gather_device(self.data)
+        return self.gather_observations(obs) if gather else obs
+
+    def rollout(self, nsteps: int, *, obs_every: int = 0, obs_out=None, obs_spec_handle=None, gather: bool = False):
         """Advance ``nsteps`` in ONE kernel launch (controller evaluated on the device).
 
         With ``obs_every = k > 0`` the flat observation of every k-th step is written on the GPU
         and returned as a torch tensor ``[nsteps // k, batch, obs_dim]``.  ``obs_spec_handle`` (a device
         ``ObsSpecHandle``) replaces the environment's own observation layout for this call (the CSV recorder's feed).
+        ``gather=True`` (sharded environments): the returned block is the all-gathered ``[nsteps // k, GLOBAL batch, obs_dim]``.
         """
         mode = self._device_mode()
         if mode is None:
@@ -181,6 +265,8 @@ class Env:
         if hasattr(ctl, "step_count"):
             ctl.step_count = self._device_steps
         data.mark_device_newer()
+        if gather and obs_out is not None:
+            return self.gather_observations(obs_out)
         return obs_out
 
     # -- host-driven path --------------------------------------------------------------------------

@@ -11,6 +11,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Phase markers of the instrumented build (oracle/mjo_flops.hpp: the same file compiled as C++ with a counting `double`; SURVEY.md
+ * §8(d) flop accounting).  No-ops here. */
+#ifndef MJO_PHASE
+#define MJO_PHASE(k) ((void)0)
+#endif
+
 #define MINVAL 1e-15
 #define MINIMP 0.0001
 #define MAXIMP 0.9999
@@ -470,6 +476,7 @@ int mjo_reset_keyframe(const mjoModel* m, mjoData* d, int key) {
 /* A1  kinematics (mj_kinematics)                                              */
 /* ------------------------------------------------------------------------- */
 static void kinematics(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_KIN);
   d->xpos[0] = d->xpos[1] = d->xpos[2] = 0;
   d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
   quat2mat(d->xmat, d->xquat);
@@ -532,6 +539,7 @@ static void kinematics(const mjoModel* m, mjoData* d) {
 /* A2  com-frame quantities (mj_comPos)                                        */
 /* ------------------------------------------------------------------------- */
 static void com_pos(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_COM);
   int nb = m->nbody;
   for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = m->body_mass[b] * d->xipos[3 * b + k];
   for (int b = nb - 1; b > 0; b--) { int p = m->body_parentid[b]; for (int k = 0; k < 3; k++) d->subtree_com[3 * p + k] += d->subtree_com[3 * b + k]; }
@@ -575,6 +583,7 @@ static void com_pos(const mjoModel* m, mjoData* d) {
 static void jac_point(const mjoModel* m, const mjoData* d, int body, const double* point, double* jacp, double* jacr);
 
 static void tendon_transmission(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_TENDON);
   int nv = m->nv;
   for (int t = 0; t < m->ntendon; t++) {
     double len = 0;
@@ -609,6 +618,7 @@ static void tendon_transmission(const mjoModel* m, mjoData* d) {
 
 /* A4  composite rigid body + dense factor (mj_crb, mj_factorM) */
 static void crb_factor(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_CRB);
   int nv = m->nv, nb = m->nbody;
   memcpy(d->crb, d->cinert, sizeof(double) * 10 * nb);
   for (int b = nb - 1; b > 0; b--) { int p = m->body_parentid[b]; if (p > 0) for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k]; }
@@ -764,6 +774,7 @@ static int capsule_capsule(const double* p1, const double* m1, const double* s1,
 }
 
 static void collision(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_COLL);
   d->ncon = 0; d->ncon_dropped = 0;
   RawCon rc[4];
   int cap = m->nconmax > 0 ? m->nconmax : m->ncon_alloc;
@@ -834,6 +845,7 @@ static int add_row(const mjoModel* m, mjoData* d, int type, int id, double pos, 
 }
 
 static void make_constraint(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_CONS);
   int nv = m->nv;
   d->nefc = 0; d->nefc_dropped = 0;
   int cap = m->nefcmax > 0 ? m->nefcmax : m->nefc_alloc;
@@ -910,6 +922,7 @@ static void make_constraint(const mjoModel* m, mjoData* d) {
 
 /* mj_referenceConstraint: efc_vel = J qvel, aref = -B vel - K imp (pos - margin) */
 static void reference_constraint(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_CONS);
   int nv = m->nv;
   for (int i = 0; i < d->nefc; i++) {
     double v = 0;
@@ -923,6 +936,7 @@ static void reference_constraint(const mjoModel* m, mjoData* d) {
 /* A7  velocity stage: com velocities, passive forces, bias forces             */
 /* ------------------------------------------------------------------------- */
 static void com_vel(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_VEL);
   memset(d->cvel, 0, sizeof(double) * 6);
   for (int b = 1; b < m->nbody; b++) {
     double cvel[6], tmp[6];
@@ -959,6 +973,7 @@ static void apply_ft(const mjoModel* m, const mjoData* d, const double* force, c
 }
 
 static void passive(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_PASSIVE);
   int nv = m->nv;
   memset(d->qfrc_passive, 0, sizeof(double) * nv);
   for (int j = 0; j < m->njnt; j++) {
@@ -1005,6 +1020,7 @@ static void passive(const mjoModel* m, mjoData* d) {
 
 /* mj_rne with flg_acc = 0: Coriolis/centrifugal + gravity */
 static void rne_bias(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_RNE);
   int nb = m->nbody, nv = m->nv;
   memset(d->cacc, 0, sizeof(double) * 6);
   d->cacc[3] = -m->gravity[0]; d->cacc[4] = -m->gravity[1]; d->cacc[5] = -m->gravity[2];
@@ -1030,6 +1046,7 @@ static void rne_bias(const mjoModel* m, mjoData* d) {
 
 /* A8  actuation (mj_fwdActuation) */
 static void actuation(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_ACT);
   int nv = m->nv;
   memset(d->qfrc_actuator, 0, sizeof(double) * nv);
   for (int a = 0; a < m->nu; a++) {
@@ -1052,6 +1069,7 @@ static void actuation(const mjoModel* m, mjoData* d) {
 
 /* A9  unconstrained acceleration (mj_fwdAcceleration) */
 static void acceleration(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_ACC);
   int nv = m->nv;
   for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_applied[i] + d->qfrc_actuator[i];
   memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof(double) * nv);
@@ -1094,6 +1112,7 @@ static double total_cost(const mjoModel* m, mjoData* d, const double* qacc, doub
 }
 static void newton_direction(const mjoModel* m, mjoData* d) {
   int nv = m->nv;
+  MJO_PHASE(MJO_PH_SOL_HESS);
   for (int i = 0; i < nv; i++) {
     double g = d->s_Ma[i] - d->qfrc_smooth[i];
     for (int r = 0; r < d->nefc; r++) g -= d->efc_J[(size_t)r * nv + i] * d->efc_force[r];
@@ -1107,10 +1126,12 @@ static void newton_direction(const mjoModel* m, mjoData* d) {
     for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; double s = D * J[i]; for (int k = 0; k <= i; k++) d->qH[i * nv + k] += s * J[k]; }
   }
   for (int i = 0; i < nv; i++) for (int k = i + 1; k < nv; k++) d->qH[i * nv + k] = d->qH[k * nv + i];
+  MJO_PHASE(MJO_PH_SOL_FACTOR);
   chol_factor(d->qH, nv);
   memcpy(d->s_Mgrad, d->s_grad, sizeof(double) * nv);
   chol_solve(d->qH, nv, d->s_Mgrad);
   for (int i = 0; i < nv; i++) d->s_search[i] = -d->s_Mgrad[i];
+  MJO_PHASE(MJO_PH_SOL_UPDATE);
 }
 /* exact minimiser of the 1-D convex piecewise-quadratic cost along `search` */
 static double line_search(const mjoModel* m, mjoData* d) {
@@ -1138,6 +1159,7 @@ static double line_search(const mjoModel* m, mjoData* d) {
 
 static void solve_constraints(const mjoModel* m, mjoData* d) {
   int nv = m->nv, nefc = d->nefc;
+  MJO_PHASE(MJO_PH_SOL_SETUP);
   d->solver_niter = 0;
   if (nefc == 0) {
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
@@ -1158,9 +1180,12 @@ static void solve_constraints(const mjoModel* m, mjoData* d) {
     double gn = 0;
     for (int i = 0; i < nv; i++) gn += d->s_grad[i] * d->s_grad[i];
     if (scale * sqrt(gn) < m->tolerance) break;
+    MJO_PHASE(MJO_PH_SOL_MATVEC);
     mul_M(m, d, d->s_Mv, d->s_search);
     mul_J(m, d, d->s_jv, d->s_search);
+    MJO_PHASE(MJO_PH_SOL_LS);
     double alpha = line_search(m, d);
+    MJO_PHASE(MJO_PH_SOL_UPDATE);
     if (alpha == 0) break;
     for (int i = 0; i < nv; i++) { d->qacc[i] += alpha * d->s_search[i]; d->s_Ma[i] += alpha * d->s_Mv[i]; }
     for (int i = 0; i < nefc; i++) d->efc_jar[i] += alpha * d->s_jv[i];
@@ -1179,6 +1204,7 @@ static void solve_constraints(const mjoModel* m, mjoData* d) {
 
 /* A12 sensors: jointpos, gyro, framequat, accelerometer (needs cacc with qacc: mj_rnePostConstraint) */
 static void sensors(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_SENSORS);
   int need_acc = 0;
   for (int s = 0; s < m->nsensor; s++) if (m->sensor_type[s] == SENS_ACCEL) need_acc = 1;
   if (need_acc) {   /* cacc <- [0; -g] + sum over ancestors of (cdof_dot qvel + cdof qacc) */
@@ -1290,6 +1316,7 @@ static int bad(const double* x, int n) { for (int i = 0; i < n; i++) if (!(fabs(
 
 /* A11 integrators */
 static void euler(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_INTEG);
   int nv = m->nv;
   double h = m->timestep;
   double* qacc = d->s_tmp;
@@ -1307,6 +1334,7 @@ static void euler(const mjoModel* m, mjoData* d) {
 
 static void rk4(const mjoModel* m, mjoData* d) {
   int nq = m->nq, nv = m->nv;
+  MJO_PHASE(MJO_PH_INTEG);
   double h = m->timestep, time0 = d->time;
   static const double A[9] = {0.5, 0, 0, 0, 0.5, 0, 0, 0, 1}, B[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
   double* X0q = dalloc(nq); double* X0v = dalloc(nv);
@@ -1327,6 +1355,7 @@ static void rk4(const mjoModel* m, mjoData* d) {
     for (int k = 0; k < nv; k++) d->qvel[k] = X0v[k] + h * da[k];
     d->time = time0 + C * h;
     mjo_forward(m, d);
+    MJO_PHASE(MJO_PH_INTEG);
     memcpy(Fv + i * nv, d->qvel, sizeof(double) * nv); memcpy(Fa + i * nv, d->qacc, sizeof(double) * nv);
   }
   memset(dv, 0, sizeof(double) * nv); memset(da, 0, sizeof(double) * nv);
@@ -1339,6 +1368,7 @@ static void rk4(const mjoModel* m, mjoData* d) {
 }
 
 void mjo_step(const mjoModel* m, mjoData* d) {
+  MJO_PHASE(MJO_PH_OTHER);
   if (bad(d->qpos, m->nq)) { d->warn_badqpos++; double t = d->time; mjo_reset(m, d); (void)t; }
   if (bad(d->qvel, m->nv)) { d->warn_badqvel++; mjo_reset(m, d); }
   mjo_forward(m, d);

@@ -28,7 +28,9 @@ def build(force: bool = False) -> str:
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        # MJO_ORACLE_LIB: another build of the same source for this process (the instrumented flop-counting build libmjo_flops.so,
+        # scripts/flop_count.py; the sanitizer build)
+        L = ctypes.CDLL(os.environ.get("MJO_ORACLE_LIB") or build())
         vp, ci, cd, cu = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_uint
         pd = ctypes.POINTER(ctypes.c_double)
         L.mjo_model_create.restype = vp

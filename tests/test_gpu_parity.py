@@ -22,15 +22,18 @@ SCALE = {"pendulum": 1.0, "cartpole": 0.005, "humanoid": 1.0, "drone2": 0.3, "ba
 
 # fp32 tolerances, per model: <= 3x the error measured on an MI355X (gpurun_out/parity_measured.json of the round-3 calibration run,
 # quoted in DESIGN.md §7); every one goes through tests.conftest.measured(), which prints the measured value when it fails.
-FWD_TOL32 = {"pendulum": 2e-5, "cartpole": 2e-5, "drone2": 2e-5, "humanoid": 2e-5, "base": 2e-5}                    # forward phases, relative
-STEP_TOL32 = {"pendulum": (2e-6, 2e-3), "cartpole": (2e-6, 2e-3), "drone2": (2e-6, 2e-3), "humanoid": (2e-6, 2e-3), "base": (2e-6, 2e-3)}
-GOLD_TQ32 = {"pendulum": 2e-4, "cartpole": 2e-4, "humanoid": 2e-4, "drone2": 2e-4}                                  # 40 free-running steps
-GOLD_AB64 = {"pendulum": 1e-5, "cartpole": 1e-5, "humanoid": 1e-4, "drone2": 1e-5}
-GOLD_AB32 = {"pendulum": 1e-3, "cartpole": 1e-3, "humanoid": 1e-1, "drone2": 1e-3}
-FD_TOL = {"pendulum": 5e-5, "cartpole": 5e-5, "drone2": 5e-5, "humanoid": 5e-5, "base": 5e-5}
-FD_CONTACT_TOL = {"float64": 1e-3, "float32": 1e-3}
-CFG5_TOL = {"hover100": 1e-4, "tf_q": 2e-6, "tf_v": 2e-3, "land_q": 2e-6, "land_v": 2e-3, "land_free_median": 1e-3}
-FB_TOL32 = {"drone2": (5e-4, 5e-3), "cartpole": (5e-4, 5e-3)}
+FWD_TOL32 = {"pendulum": 1.5e-6, "cartpole": 1e-6, "drone2": 8e-7, "humanoid": 2e-5, "base": 9e-7}              # forward phases, relative (humanoid measured 1.2e-5)
+STEP_TOL32 = {"pendulum": (3.2e-8, 1.6e-7), "cartpole": (3.5e-7, 1.1e-5), "drone2": (1.4e-6, 4e-6), "humanoid": (2e-6, 3.5e-4), "base": (3.2e-8, 5e-6)}
+GOLD_TQ32 = {"pendulum": 2.2e-8, "cartpole": 1.1e-7, "humanoid": 9e-5, "drone2": 3.3e-7}                           # 40 free-running steps
+GOLD_AB64 = {"pendulum": 1e-10, "cartpole": 2e-10, "humanoid": 3e-9, "drone2": 9e-10}
+GOLD_AB32 = {"pendulum": 1e-10, "cartpole": 1.2e-9, "humanoid": 4.5e-5, "drone2": 6.5e-9}
+FD_TOL = {"pendulum": 5e-11, "cartpole": 2.5e-10, "drone2": 1e-10, "humanoid": 9e-8, "base": 5e-10}
+FD_CONTACT_TOL = {"float64": 3e-9, "float32": 3.5e-9}
+CFG5_TOL = {"hover100": 4e-6, "tf_q": 2e-6, "tf_v": 3.3e-5, "land_q": 4e-7, "land_v": 7.5e-6, "land_free_median": 2e-6}
+FB_TOL32 = {"drone2": (3.6e-7, 2.4e-6), "cartpole": (2.6e-7, 3.2e-7)}
+MISC_TOL32 = {"capsules_con": 1.15e-7, "capsules_J": 1.7e-7, "capsules_step": 1.3e-7, "pairs_con": 2.3e-6, "pairs_normal": 4.2e-6, "pairs_steps": 5e-6,
+              "sliding_box_20": 2.5e-7, "sensors": 1.05e-6, "inverse_humanoid": 2.1e-4, "cartpole_100": 9.6e-6, "cartpole_1000_median": 4.7e-5,
+              "humanoid_20_max": 9.3e-5, "humanoid_60_median": 6.2e-5, "humanoid_60_p90": 2.8e-4, "jac_drone": 1e-15}
 
 
 @pytest.fixture(scope="module")
@@ -115,18 +118,18 @@ def test_parallel_capsules_two_contacts(dtype):
     assert cn["ncon"].tolist() == [2, 2, 2] and cn["nefc"].tolist() == [8, 8, 8]
     con = sim.debug_get("con").reshape(3, sim.nconmax, 11)[0, :2]
     ref = od.contacts()
-    tol = 1e-12 if dtype == "float64" else 2e-7
-    assert np.abs(con[:, 0] - ref["dist"]).max() <= tol and np.abs(con[:, 1:4] - ref["pos"]).max() <= tol
+    tol = 1e-12 if dtype == "float64" else MISC_TOL32["capsules_con"]
+    measured(f"parallel_capsules/contact/{dtype}", max(np.abs(con[:, 0] - ref["dist"]).max(), np.abs(con[:, 1:4] - ref["pos"]).max()), tol)
     assert sorted(con[:, 1].tolist()) == pytest.approx([-0.15, 0.25], abs=tol)            # the hand-derived anchor
     J = sim.debug_get("efc_J").reshape(3, sim.nefcmax, cm.nv)[0, :8]
-    assert np.abs(J - od.efc_J.reshape(8, cm.nv)).max() <= (1e-12 if dtype == "float64" else 1e-6)
+    measured(f"parallel_capsules/J/{dtype}", np.abs(J - od.efc_J.reshape(8, cm.nv)).max(), 1e-12 if dtype == "float64" else MISC_TOL32["capsules_J"])
     # float64 follows the oracle through the |det| < 1e-15 switch step after step; fp32 keeps the two-contact branch while the axes
     # stay within 1e-3 rad (the oracle leaves it after the first step's 1e-10 rad of relative rotation), so only ONE step is compared
     nstep = 20 if dtype == "float64" else 1
     sim.step(nstep)
     for _ in range(nstep):
         od.step()
-    assert np.abs(sim.get("qpos")[0] - od.qpos).max() <= (1e-10 if dtype == "float64" else 2e-6)
+    measured(f"parallel_capsules/steps/{dtype}", np.abs(sim.get("qpos")[0] - od.qpos).max(), 1e-10 if dtype == "float64" else MISC_TOL32["capsules_step"])
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -145,16 +148,16 @@ def test_non_plane_primitive_pairs_match_the_hand_derived_geometry(dtype):
     assert sim.counters()["ncon"].tolist() == [4, 4]
     con = sim.debug_get("con").reshape(2, sim.nconmax, 11)[1, :4]
     ref = od.contacts()
-    tol = 1e-12 if dtype == "float64" else 3e-6                     # fp32: positions up to 30 m from the origin
-    assert np.abs(con[:, 0] - ref["dist"]).max() <= tol and np.abs(con[:, 1:4] - ref["pos"]).max() <= tol
-    assert np.abs(con[:, 4:7] - ref["frame"][:, 0, :]).max() <= (1e-12 if dtype == "float64" else 1e-5)
+    tol = 1e-12 if dtype == "float64" else MISC_TOL32["pairs_con"]  # fp32: positions up to 30 m from the origin
+    measured(f"primitive_pairs/contact/{dtype}", max(np.abs(con[:, 0] - ref["dist"]).max(), np.abs(con[:, 1:4] - ref["pos"]).max()), tol)
+    measured(f"primitive_pairs/normal/{dtype}", np.abs(con[:, 4:7] - ref["frame"][:, 0, :]).max(), 1e-12 if dtype == "float64" else MISC_TOL32["pairs_normal"])
     dv = float(np.hypot(0.1, 0.08))
     assert sorted(con[:, 0].tolist()) == pytest.approx(sorted([-0.05, dv - 0.15, -0.03, -0.05]), abs=tol)     # the hand-derived anchor
     nstep = 10
     sim.step(nstep)
     for _ in range(nstep):
         od.step()
-    assert np.abs(sim.get("qpos")[1] - od.qpos).max() <= (1e-10 if dtype == "float64" else 5e-6)
+    measured(f"primitive_pairs/steps/{dtype}", np.abs(sim.get("qpos")[1] - od.qpos).max(), 1e-10 if dtype == "float64" else MISC_TOL32["pairs_steps"])
     assert np.abs(od.qvel).max() > 1e-3                              # the contacts really pushed
 
 
@@ -171,7 +174,7 @@ def test_sliding_box_four_corner_contacts_with_friction():
     ods = [mjo.OracleData(om) for _ in range(B)]
     for e, od in enumerate(ods):
         od.qvel[:] = v0[e]
-    for dtype, steps, tol in (("float64", 300, 1e-9), ("float32", 20, 1e-4)):
+    for dtype, steps, tol in (("float64", 300, 1e-9), ("float32", 20, MISC_TOL32["sliding_box_20"])):
         for e, od in enumerate(ods):
             od.reset(); od.qvel[:] = v0[e]
             for _ in range(steps):
@@ -179,7 +182,7 @@ def test_sliding_box_four_corner_contacts_with_friction():
         sim = BatchSim(dm, B, dtype=dtype)
         sim.set("qvel", v0)
         sim.step(steps)
-        assert np.abs(sim.get("qpos") - np.stack([od.qpos for od in ods])).max() <= tol, dtype
+        measured(f"sliding_box/{dtype}/{steps}_steps", np.abs(sim.get("qpos") - np.stack([od.qpos for od in ods])).max(), tol)
         assert sim.counters()["efc_dropped"].sum() == 0
     assert np.stack([od.qvel for od in ods])[:, 0].max() < 2.0 - 0.8 * 0.5 * 9.81 * 0.04         # 20 steps: friction took >= 80 % of mu g t off the speed
 
@@ -280,12 +283,12 @@ def test_cartpole_config2_drift(world):
     sim.set("qpos", q)
     sim.rollout(100, CTRL_RANDOM, seed=1, ctrl_scale=0.005)
     q100, _ = mjo.rollout_batch(om, B, 100, seed=1, scale=0.005, nthreads=8, qpos_init=q)
-    assert np.abs(sim.get("qpos") - q100).max() <= 1e-4
+    measured("config2/cartpole_1024/fp32_drift_100_steps_max", np.abs(sim.get("qpos") - q100).max(), MISC_TOL32["cartpole_100"])
     sim.rollout(900, CTRL_RANDOM, seed=1, step0=100, ctrl_scale=0.005)
     q1000, _ = mjo.rollout_batch(om, B, 1000, seed=1, scale=0.005, nthreads=8, qpos_init=q)
     err = np.abs(sim.get("qpos") - q1000).max(axis=1)
     print(f"cartpole 1000-step fp32 drift: median {np.median(err):.2e} max {err.max():.2e} frac>1e-4 {(err > 1e-4).mean():.3f}")
-    assert np.median(err) <= 1e-3
+    measured("config2/cartpole_1024/fp32_drift_1000_steps_median", np.median(err), MISC_TOL32["cartpole_1000_median"], f"(max {err.max():.2e}, reported not bounded)")
     assert np.isfinite(sim.get("qpos")).all() and sim.counters()["efc_dropped"].sum() == 0
 
 
@@ -337,14 +340,14 @@ def test_sensors_match_oracle(world):
     q, v, u = random_states(cm, ods[0], B, 21, qs=0.2, vs=0.5)
     q[:, 2] += 1.0
     u = (u + 1) * 3.0
-    for dtype, tol in (("float64", 1e-11), ("float32", 2e-4)):
+    for dtype, tol in (("float64", 1e-11), ("float32", MISC_TOL32["sensors"])):
         sim = BatchSim(dm, B, dtype=dtype)
         sim.set("qpos", q); sim.set("qvel", v); sim.set("ctrl", u)
         sim.step(1)
         for e, od in enumerate(ods):
             od.reset(); od.qpos[:] = q[e]; od.qvel[:] = v[e]; od.ctrl[:] = u[e]; od.step()
         ref = np.stack([od.sensordata for od in ods])
-        assert np.abs(sim.get("sensordata") - ref).max() <= tol * max(1.0, np.abs(ref).max())
+        measured(f"sensors/drone2/{dtype}", np.abs(sim.get("sensordata") - ref).max() / max(1.0, np.abs(ref).max()), tol, "(relative to the largest reading)")
 
 
 def test_caps_drop_the_same_rows_as_the_oracle(world):
@@ -465,7 +468,7 @@ def test_jacobians_match_oracle(world):
     jp, jr = simd.jac([0], [cmd.name2id(mjcf.OBJ_SITE, "thrust3")])
     odd = mjo.OracleData(omd); odd.forward()
     op, orr = odd.jac(0, cmd.name2id(mjcf.OBJ_SITE, "thrust3"))
-    assert np.abs(jp[0, 0] - op).max() < 1e-7 and np.abs(jr[0, 0] - orr).max() < 1e-7
+    measured("jacobians/drone2/fp32_state", max(np.abs(jp[0, 0] - op).max(), np.abs(jr[0, 0] - orr).max()), MISC_TOL32["jac_drone"])
 
 
 def test_full_size_humanoid_properties(world):
@@ -497,11 +500,12 @@ def test_full_size_humanoid_properties(world):
     sim = BatchSim(dm, S, dtype="float32")
     sim.rollout(20, CTRL_RANDOM, seed=0)
     qo, _ = mjo.rollout_batch(om, S, 20, seed=0, nthreads=8)
-    assert np.abs(sim.get("qpos") - qo).max() < 1e-4                         # the whole sample inside BASELINE's bound at 20 steps
+    measured("config3/humanoid_64/fp32_drift_20_steps_max", np.abs(sim.get("qpos") - qo).max(), MISC_TOL32["humanoid_20_max"])   # the whole sample inside BASELINE's bound at 20 steps
     sim.rollout(40, CTRL_RANDOM, seed=0, step0=20)
     qo, _ = mjo.rollout_batch(om, S, 60, seed=0, nthreads=8)
     err = np.abs(sim.get("qpos") - qo).max(axis=1)
-    assert np.median(err) < 1e-4 and np.quantile(err, 0.9) < 5e-4, (np.median(err), np.quantile(err, 0.9), err.max())
+    measured("config3/humanoid_64/fp32_drift_60_steps_median", np.median(err), MISC_TOL32["humanoid_60_median"])
+    measured("config3/humanoid_64/fp32_drift_60_steps_p90", np.quantile(err, 0.9), MISC_TOL32["humanoid_60_p90"], f"(max {err.max():.2e})")
 
 
 def test_device_feedback_controller_matches_host_law(world):
@@ -549,7 +553,7 @@ def test_device_feedback_controller_matches_host_law(world):
         BatchSim(world("cartpole")[2], 2).rollout(1, 3)          # feedback mode without gains
 
 
-@pytest.mark.parametrize("name,dtype,tol", [("humanoid", "float64", 1e-9), ("humanoid", "float32", 2e-3), ("drone2", "float64", 1e-10)])
+@pytest.mark.parametrize("name,dtype,tol", [("humanoid", "float64", 1e-9), ("humanoid", "float32", None), ("drone2", "float64", 1e-10)])
 def test_inverse_dynamics_matches_oracle(world, name, dtype, tol):
     """mjb_inverse (reference setpoints.py:29-31) on states with contacts, random qacc: qfrc_inverse and the dense
     actuator moment vs the oracle.  fp32 tolerance: relative to the largest generalized force (M qacc cancels bias)."""
@@ -570,7 +574,10 @@ def test_inverse_dynamics_matches_oracle(world, name, dtype, tol):
     got = sim.get("qfrc_inverse"); mom = sim.get("actuator_moment")
     for e in range(B):
         ref = ods[e].qfrc_inverse
-        assert np.abs(got[e] - ref).max() <= tol * max(1.0, np.abs(ref).max()), e
+        if dtype == "float64":
+            assert np.abs(got[e] - ref).max() <= tol * max(1.0, np.abs(ref).max()), e
+        else:
+            measured(f"inverse_dynamics/{name}/fp32", np.abs(got[e] - ref).max() / max(1.0, np.abs(ref).max()), MISC_TOL32["inverse_humanoid"], "(relative to the largest generalized force)")
         assert np.abs(mom[e] - ods[e].actuator_moment).max() <= (1e-12 if dtype == "float64" else 1e-5)
     assert np.array_equal(sim.get("qacc"), a if dtype == "float64" else a.astype(np.float32).astype(np.float64))
 

@@ -143,6 +143,41 @@ def test_gloo_world_size_2_all_gather_obs(tmp_path):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
 
 
+def test_gloo_world_size_2_shard_plan_gather_equals_the_one_rank_block(tmp_path):
+    """What a sharded ``Env`` does on the N > 1 path, on CPU ranks (the Env itself needs a GPU: tests/test_gpu_env_api.py runs the same
+    through ``Env.from_xml_path(..., shard=True)`` with two gloo ranks on the GPU box): ``ShardPlan.from_environment`` reads the
+    torchrun environment, every rank fills ITS block of a table indexed by the GLOBAL environment index, ``ShardPlan.gather`` returns
+    the whole table on every rank - bitwise the one-rank table - for equal (10) and ragged (9 = 5 + 4) global batches; a global batch
+    smaller than the world is refused."""
+    script = tmp_path / "worker_plan.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from mujoco_template_amd.distributed import ShardPlan, init_process_group\n"
+        "assert init_process_group('gloo')\n"
+        "for B in (10, 9):\n"
+        "    plan = ShardPlan.from_environment(B)\n"
+        "    assert plan.world_size == 2 and sum(plan.counts) == B and plan.env0 == (0 if plan.rank == 0 else plan.counts[0])\n"
+        "    one = ShardPlan.from_environment(B, rank=0, world_size=1)\n"
+        "    table = lambda e0, c: (torch.arange(e0, e0 + c, dtype=torch.float32)[None, :, None] * 1000 + torch.arange(3, dtype=torch.float32)[:, None, None] * 10 + torch.arange(7, dtype=torch.float32)[None, None, :])\n"
+        "    full = one.gather(table(one.env0, one.count))               # one rank: the identity\n"
+        "    out = plan.gather(table(plan.env0, plan.count))\n"
+        "    assert out.shape == (3, B, 7) and torch.equal(out, full), (plan, out.shape)\n"
+        "try:\n"
+        "    ShardPlan.from_environment(1)\n"
+        "    raise SystemExit('a global batch of 1 on 2 ranks must be refused')\n"
+        "except ValueError:\n"
+        "    pass\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        f"open(os.path.join({str(tmp_path)!r}, 'plan_ok_%d' % plan.rank), 'w').write('ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "plan_ok_0").exists() and (tmp_path / "plan_ok_1").exists()
+
+
 def test_gloo_single_rank_group_issues_the_collective(tmp_path):
     """single_rank=True (the one-GPU rehearsal switch of bench.py under torchrun): a ONE-rank group is initialised and the all-gather is
     really issued instead of short-circuiting; without RANK in the environment nothing is initialised."""
