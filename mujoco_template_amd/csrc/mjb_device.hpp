@@ -615,6 +615,12 @@ MJB_DEV void reg_factor32(MRef m, const T* M, T* W, T* dinv, const T* J, const T
 // one MFMA per pair of constraint rows.  Forward substitution is fused; L goes to LDS (packed) for the
 // backward substitution and for reuse when the active set does not change.
 // ---------------------------------------------------------------------------
+#ifndef MJB_PANEL4
+#define MJB_PANEL4 0             // experiment (round 3, off): FOUR pivots per panel in the MFMA sweep inverse instead of two.  Measured in
+#endif                           // scripts/micro/factor_bench (profiles/r03_panel4_microbench.log): panel loop 4682 -> 4374 cycles alone, 5210 -> 4595 with two
+                                 // waves per SIMD, same residual - about 1 % of a step.  Not adopted: a wave issues one VALU instruction per >= 4 cycles
+                                 // whatever it does, and the 4x4 scalar elimination (10 v_readlane, 4 rcp, 20 dependent FMAs) costs as many instructions
+                                 // per pivot as two 2x2 ones; halving the MFMA round trips alone buys little, and the rounding of every solve would change.
 #ifndef MJB_SWEEP_EXCLUDE
 #define MJB_SWEEP_EXCLUDE 1      // factor_W mode that keeps the Cholesky path (1 = Hessian); -1: sweep everywhere
 #endif
@@ -844,6 +850,41 @@ MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, con
     }
   }
   unsigned long long tq1 = pf ? MJB_MEMTIME() : 0;
+#if MJB_PANEL4
+  // FOUR pivots per panel (experiment, see MJB_PANEL4 above).  Columns j0..j0+3 are rows 8q+4h+t of ONE half, registers 4q..4q+3.
+  // Block elimination  B <- B - U P^-1 U^T  with P = L D L^T (unit lower L, in scalars):  W = U' L^-T  (per lane: three dependent
+  // FMAs),  Z = W D^-1,  B -= Z W^T  as two rank-2 MFMAs;  U' = U - [e_j0 .. e_j3] makes the same products deliver the pivot rows /
+  // columns and -P^-1 up to a -2 on the four pivot diagonals (as in the two-pivot form).
+#pragma unroll
+  for (int jq = 0; jq < 8; jq++) {
+    const int j0 = 4 * jq, hj = jq & 1, ij = 4 * (jq >> 1);
+    if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
+    int c = c_, ln = lane;
+    MJB_OPAQUE2(c, ln);                     // keep the per-column lane compares in the loop (cheaper than spilled masks)
+    const float u0 = half_bcast(acc[ij], hj), u1 = half_bcast(acc[ij + 1], hj), u2 = half_bcast(acc[ij + 2], hj), u3 = half_bcast(acc[ij + 3], hj);
+    const float tiny = Num<float>::minval();
+    const float a00 = __builtin_fmaxf(rdlane_f(u0, j0), tiny), a10 = rdlane_f(u0, j0 + 1), a20 = rdlane_f(u0, j0 + 2), a30 = rdlane_f(u0, j0 + 3);
+    const float a11 = rdlane_f(u1, j0 + 1), a21 = rdlane_f(u1, j0 + 2), a31 = rdlane_f(u1, j0 + 3);
+    const float a22 = rdlane_f(u2, j0 + 2), a32 = rdlane_f(u2, j0 + 3), a33 = rdlane_f(u3, j0 + 3);
+    const float i0 = MJB_RCPF(a00);
+    const float l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const float d1 = __builtin_fmaxf(a11 - l10 * a10, a11 * tiny), i1 = MJB_RCPF(d1);
+    const float t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
+    const float l21 = t21 * i1, l31 = t31 * i1;
+    const float d2 = __builtin_fmaxf(a22 - l20 * a20 - l21 * t21, a22 * tiny), i2 = MJB_RCPF(d2);
+    const float t32 = a32 - l30 * a20 - l31 * t21;
+    const float l32 = t32 * i2;
+    const float d3 = __builtin_fmaxf(a33 - l30 * a30 - l31 * t31 - l32 * t32, a33 * tiny), i3 = MJB_RCPF(d3);
+    const float w0 = c == j0 ? u0 - 1.0f : u0;
+    const float w1 = (c == j0 + 1 ? u1 - 1.0f : u1) - l10 * w0;
+    const float w2 = (c == j0 + 2 ? u2 - 1.0f : u2) - l20 * w0 - l21 * w1;
+    const float w3 = (c == j0 + 3 ? u3 - 1.0f : u3) - l30 * w0 - l31 * w1 - l32 * w2;
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[ij + t] -= ln == 32 * hj + j0 + t ? 2.0f : 0.0f;
+    acc = MJB_MFMA(h == 0 ? -(w0 * i0) : -(w1 * i1), h == 0 ? w0 : w1, acc);
+    acc = MJB_MFMA(h == 0 ? -(w2 * i2) : -(w3 * i3), h == 0 ? w2 : w3, acc);
+  }
+#else
 #pragma unroll
   for (int jb = 0; jb < 16; jb++) {
     const int j0 = 2 * jb, j1 = j0 + 1, hj = (j0 >> 2) & 1, ij = 4 * (j0 >> 3) + (j0 & 3);
@@ -863,6 +904,7 @@ MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, con
     acc[ij + 1] -= ln == 32 * hj + j1 ? 2.0f : 0.0f;
     acc = MJB_MFMA(aop, bop, acc);
   }
+#endif
   if (pf) { unsigned long long tq2 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; }
   return acc;
 }

@@ -66,6 +66,7 @@ struct mjoModel {
   /* keyframes */
   double *key_qpos, *key_qvel, *key_ctrl, *key_time;
   int has_damping;
+  int round_mask;                 /* precision study only (mjo_set_round_mask): which phases' outputs are rounded to fp32; 0 everywhere else */
 };
 
 typedef struct {
@@ -357,6 +358,7 @@ void mjo_model_free(mjoModel* m) {
 void mjo_set_disableactuator(mjoModel* m, int mask) { m->disableactuator = mask; }
 void mjo_set_limits(mjoModel* m, int nconmax, int nefcmax) { m->nconmax = nconmax; m->nefcmax = nefcmax; }
 void mjo_set_solver(mjoModel* m, int iterations, double tolerance) { m->iterations = iterations; m->tolerance = tolerance; }
+void mjo_set_round_mask(mjoModel* m, int mask) { m->round_mask = mask; }
 
 /* ------------------------------------------------------------------------- */
 /* data                                                                        */
@@ -1244,20 +1246,43 @@ static void sensors(const mjoModel* m, mjoData* d) {
 /* ------------------------------------------------------------------------- */
 /* mj_forward                                                                   */
 /* ------------------------------------------------------------------------- */
+/* Precision study (scripts/precision_study.py): the outputs of the phases named in m->round_mask are rounded to fp32
+ * where they are handed to the next phase - an fp32-STORAGE model of a mixed-precision kernel (the arithmetic inside a phase stays
+ * float64, so the error it shows is a lower bound for a real fp32 phase).  round_mask is 0 in every other use of the oracle. */
+static void r32(double* x, long n) { for (long i = 0; i < n; i++) x[i] = (double)(float)x[i]; }
+enum { RM_KIN = 1, RM_COM = 2, RM_CRB = 4, RM_CONS = 8, RM_VEL = 16, RM_RNE = 32, RM_FRC = 64, RM_ACC = 128, RM_SOLVER = 256, RM_STATE = 512 };
+
 void mjo_forward(const mjoModel* m, mjoData* d) {
+  const int rm = m->round_mask, nv = m->nv, nb = m->nbody;
   kinematics(m, d);
+  if (rm & RM_KIN) {
+    r32(d->xpos, 3L * nb); r32(d->xquat, 4L * nb); r32(d->xmat, 9L * nb); r32(d->xipos, 3L * nb); r32(d->ximat, 9L * nb);
+    r32(d->xanchor, 3L * m->njnt); r32(d->xaxis, 3L * m->njnt); r32(d->geom_xpos, 3L * m->ngeom); r32(d->geom_xmat, 9L * m->ngeom);
+    r32(d->site_xpos, 3L * m->nsite); r32(d->site_xmat, 9L * m->nsite);
+  }
   com_pos(m, d);
+  if (rm & RM_COM) { r32(d->subtree_com, 3L * nb); r32(d->cinert, 10L * nb); r32(d->cdof, 6L * nv); }
   tendon_transmission(m, d);
   crb_factor(m, d);
+  if (rm & RM_CRB) { r32(d->crb, 10L * nb); r32(d->qM, (long)nv * nv); memcpy(d->qL, d->qM, sizeof(double) * nv * nv); chol_factor(d->qL, nv); r32(d->qL, (long)nv * nv); }
   collision(m, d);
   make_constraint(m, d);
   com_vel(m, d);
+  if (rm & RM_VEL) { r32(d->cvel, 6L * nb); r32(d->cdof_dot, 6L * nv); }
   passive(m, d);
   reference_constraint(m, d);
+  if (rm & RM_CONS) {
+    for (int i = 0; i < d->ncon; i++) { r32(&d->contact[i].dist, 1); r32(d->contact[i].pos, 3); r32(d->contact[i].frame, 9); }
+    r32(d->efc_J, (long)d->nefc * nv); r32(d->efc_pos, d->nefc); r32(d->efc_D, d->nefc); r32(d->efc_R, d->nefc); r32(d->efc_aref, d->nefc);
+  }
   rne_bias(m, d);
+  if (rm & RM_RNE) { r32(d->cacc, 6L * nb); r32(d->cfrc, 6L * nb); r32(d->qfrc_bias, nv); }
   actuation(m, d);
+  if (rm & RM_FRC) { r32(d->qfrc_passive, nv); r32(d->qfrc_actuator, nv); }
   acceleration(m, d);
+  if (rm & RM_ACC) { r32(d->qfrc_smooth, nv); r32(d->qacc_smooth, nv); }
   solve_constraints(m, d);
+  if (rm & RM_SOLVER) { r32(d->qacc, nv); r32(d->qacc_warmstart, nv); r32(d->qfrc_constraint, nv); r32(d->efc_force, d->nefc); }
   sensors(m, d);
 }
 
@@ -1374,6 +1399,7 @@ void mjo_step(const mjoModel* m, mjoData* d) {
   mjo_forward(m, d);
   if (bad(d->qacc, m->nv)) { d->warn_badqacc++; mjo_reset(m, d); mjo_forward(m, d); }
   if (m->integrator == INT_RK4) rk4(m, d); else euler(m, d);
+  if (m->round_mask & RM_STATE) { r32(d->qpos, m->nq); r32(d->qvel, m->nv); }      /* precision study: fp32 state storage */
 }
 
 /* ------------------------------------------------------------------------- */

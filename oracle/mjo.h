@@ -39,6 +39,8 @@ const char* mjo_last_error(void);
 void mjo_set_disableactuator(mjoModel* m, int mask);
 void mjo_set_limits(mjoModel* m, int nconmax, int nefcmax);   /* 0 = unlimited (default) */
 void mjo_set_solver(mjoModel* m, int iterations, double tolerance);
+/* precision study only: bit k set = the outputs of phase k are rounded to fp32 (fp32-storage model); 0 = the oracle proper */
+void mjo_set_round_mask(mjoModel* m, int mask);
 
 mjoData* mjo_data_create(const mjoModel* m);
 void mjo_data_free(mjoData* d);

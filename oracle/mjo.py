@@ -40,6 +40,7 @@ def lib() -> ctypes.CDLL:
         L.mjo_set_disableactuator.argtypes = [vp, ci]
         L.mjo_set_limits.argtypes = [vp, ci, ci]
         L.mjo_set_solver.argtypes = [vp, ci, cd]
+        L.mjo_set_round_mask.argtypes = [vp, ci]
         L.mjo_data_create.restype = vp
         L.mjo_data_create.argtypes = [vp]
         L.mjo_data_free.argtypes = [vp]
@@ -92,6 +93,10 @@ class OracleModel:
 
     def set_solver(self, iterations: int, tolerance: float) -> None:
         lib().mjo_set_solver(self.ptr, int(iterations), float(tolerance))
+
+    def set_round_mask(self, mask: int) -> None:
+        """Precision study only: round the outputs of the phases in ``mask`` to fp32 (oracle/mjo.c RM_*); 0 = the oracle proper."""
+        lib().mjo_set_round_mask(self.ptr, int(mask))
 
     def __del__(self):
         try:
