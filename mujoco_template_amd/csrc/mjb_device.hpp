@@ -229,10 +229,25 @@ template <typename T> MJB_DEV void cross3(T* r, const T* a, const T* b) {
   T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
+// fp32: 1 / |a| as v_rsq_f32 + one Newton step (t_rsqrt: full single precision, ~5 instructions) instead of the correctly rounded
+// sqrt followed by a correctly rounded division (~22): normalisations are all over the position stage (every body, geom, contact
+// frame).  float64 keeps sqrt and division (the validation path is held to 1e-12 against the oracle).
 template <typename T> MJB_DEV T normalize3(T* a) {
-  T n = t_sqrt(dot3(a, a));
-  if (n < Num<T>::minval()) { a[0] = 1; a[1] = 0; a[2] = 0; } else { T s = 1 / n; a[0] *= s; a[1] *= s; a[2] *= s; }
-  return n;
+  const T n2 = dot3(a, a);
+#ifdef MJB_R2_KINEMATICS
+  if constexpr (false) {
+#else
+  if constexpr (sizeof(T) == 4) {
+#endif
+    if (n2 < Num<T>::minval() * Num<T>::minval()) { a[0] = 1; a[1] = 0; a[2] = 0; return t_sqrt(n2); }
+    const T s = t_rsqrt(n2);
+    a[0] *= s; a[1] *= s; a[2] *= s;
+    return n2 * s;
+  } else {
+    T n = t_sqrt(n2);
+    if (n < Num<T>::minval()) { a[0] = 1; a[1] = 0; a[2] = 0; } else { T s = 1 / n; a[0] *= s; a[1] *= s; a[2] *= s; }
+    return n;
+  }
 }
 template <typename T> MJB_DEV void mulmatvec3(T* r, const T* m, const T* v) {
   T x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
@@ -250,8 +265,19 @@ template <typename T> MJB_DEV void quat_mul(T* r, const T* a, const T* b) {
   r[0] = w; r[1] = x; r[2] = y; r[3] = z;
 }
 template <typename T> MJB_DEV void quat_normalize(T* q) {
-  T n = t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < Num<T>::minval()) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { T s = 1 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+  const T n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+#ifdef MJB_R2_KINEMATICS
+  if constexpr (false) {
+#else
+  if constexpr (sizeof(T) == 4) {
+#endif
+    if (n2 < Num<T>::minval() * Num<T>::minval()) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+    const T s = t_rsqrt(n2);
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+  } else {
+    T n = t_sqrt(n2);
+    if (n < Num<T>::minval()) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { T s = 1 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+  }
 }
 template <typename T> MJB_DEV void quat2mat(T* m, const T* q) {
   T w = q[0], x = q[1], y = q[2], z = q[3];
@@ -1178,8 +1204,55 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
     for (int k = 0; k < 4; k++) xquat[4 * b + k] = quat[k];
   }
   gsync<G>();
-  // (2) compose down the tree, in place
-  {
+  // (2) compose down the tree, in place.
+  // Round 3: POINTER JUMPING instead of one pass per tree level.  The per-level loop ran nlevel (humanoid: 7) dependent rounds with
+  // one to four lanes active each (mean 7.3 active lanes over the whole phase, profiles/r03_phase_table.txt: the worst of the
+  // kernel) - ~105 instructions per level whatever the number of bodies in it.  Rigid transforms compose associatively, so every
+  // body can instead double the distance to the ancestor its pose is relative to: round r composes the pose of body b (relative
+  // to its ancestor at distance 2^r) with the pose of THAT ancestor (itself relative to its own ancestor at distance 2^r); after
+  // ceil(log2(nlevel)) rounds (3) every pose is relative to the world.  All bodies work in every round (16 lanes), every round
+  // reads all its inputs, syncs, then writes.  The unit quaternion is re-normalised ONCE per body at the end (the level loop did
+  // it per level, like mj_kinematics; the product of unit quaternions stays unit to rounding) - results differ from the
+  // sequential composition in the last bits only (float64 instantiation vs the oracle: <= 1e-15).
+#ifdef MJB_R2_KINEMATICS                                            // A/B timing against the round-2 form (scripts/gpu_perf_quick.py)
+  if (false) {
+#else
+  if (m.nbody - 1 <= G) {
+#endif
+    const int b = 1 + lane, nl = m.nlevel;
+    const bool own = b < m.nbody;
+    const int dep = own ? m.body_depth[b] : 0;
+    for (int d = 1; d < nl; d <<= 1) {
+      const bool hop = own && d <= dep - 1;                        // an ancestor at distance d exists below the world body
+      T pq[4], pp[3], lq[4], lp[3], q[4], t[3];
+      if (hop) {
+        const int a = m.body_anc[b * nl + d - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { pq[k] = xquat[4 * a + k]; lq[k] = xquat[4 * b + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pp[k] = xpos[3 * a + k]; lp[k] = xpos[3 * b + k]; }
+        quat_mul(q, pq, lq);
+        quat_rot(t, pq, lp);
+      }
+      gsync<G>();                                                   // every read of this round before any write
+      if (hop) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) xquat[4 * b + k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) xpos[3 * b + k] = pp[k] + t[k];
+      }
+      gsync<G>();
+    }
+    if (own) {
+      T q[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) q[k] = xquat[4 * b + k];
+      quat_normalize(q);
+#pragma unroll
+      for (int k = 0; k < 4; k++) xquat[4 * b + k] = q[k];
+    }
+    gsync<G>();
+  } else {                                                          // more bodies than lanes: one pass per tree level
     const int b0 = 1 + lane;
     int dep0 = -1, par0 = 0;                                    // the lane's body: depth and parent stay in registers
     if (b0 < m.nbody) { dep0 = m.body_depth[b0]; par0 = m.body_parentid[b0]; }

@@ -15,8 +15,8 @@ from mujoco_template_amd import runtime  # noqa: E402
 from tests.conftest import BASE_XML, MODELS, measured  # noqa: E402
 
 # fp32 tolerances of the parity-type checks in this file: <= 3x the error measured on an MI355X (gpurun_out/parity_measured.json)
-API_TOL32 = {"gemm": {"humanoid": 7e-7, "drone2": 2.7e-7, "cartpole": 7.5e-8}, "gemm_fused": {"humanoid": 7e-7, "drone2": 5.3e-7, "cartpole": 9e-8},
-             "lqr_1000_pair": 1.9e-5, "lqr_1000_oracle": 1.4e-5, "pid_300_oracle": 4.5e-7, "pid_300_pair": 2.5e-6}
+API_TOL32 = {"gemm": {"humanoid": 7e-7, "drone2": 2.7e-7, "cartpole": 7.5e-8}, "gemm_fused": {"humanoid": 7.1e-7, "drone2": 5.4e-7, "cartpole": 8.8e-8},
+             "lqr_1000_pair": 2.8e-5, "lqr_1000_oracle": 2.0e-5, "pid_300_oracle": 9.0e-7, "pid_300_pair": 2.5e-6}
 
 
 @pytest.fixture
