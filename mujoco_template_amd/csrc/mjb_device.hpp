@@ -2025,7 +2025,8 @@ template <typename T, int G> MJB_DEV void vel_bias_passive(Ctx<T>& c) {
 // ---------------------------------------------------------------------------
 // A8/A9 actuation and unconstrained acceleration
 // ---------------------------------------------------------------------------
-template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
+// actuator forces -> qfrc_actuator, qfrc_smooth (and the right-hand side of the M^-1 solve in qacc_smooth)
+template <typename T, int G> MJB_DEV void actuation_forces(Ctx<T>& c) {
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv;
   T *ctrl = w + L.ctrl, *af = w + L.act_force, *qpos = w + L.qpos, *qvel = w + L.qvel;
   for (int a = lane; a < m.nu; a += G) {
@@ -2072,7 +2073,10 @@ template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
     qs[i] = fs; qas[i] = fs;
   }
   gsync<G>();
-  factor_W<T, G>(c, 0, qas);
+}
+template <typename T, int G> MJB_DEV void actuation_acceleration(Ctx<T>& c) {
+  actuation_forces<T, G>(c);
+  factor_W<T, G>(c, 0, c.w + c.lp->qacc_smooth);
 }
 
 // ---------------------------------------------------------------------------
@@ -2935,23 +2939,40 @@ MJB_DEV void env_run2(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, 
     }
     mjb_f16v inv;
     for (int pass = 0; pass < 2; pass++) {                      // pass 1 only after a bad-acceleration reset (like k_step's retry)
+      // Round 3 schedule (the M^-1 solve leaves wave 0's critical path; wave 1, idle through most of the solver before, carries the
+      // velocity stage and both sweep inverses):
+      //     wave 0:  kinematics | com_pos        | crb -> [M ready] -> constraint rows | actuator forces |              | Newton solver, sensors |        |
+      //     wave 1:   (waits)   | collision      | bias / passive forces -> -M^-1      |   (waits)       | M^-1 f       | -(M + h D)^-1          | Euler  |
+      // "M ready" is one LDS word wave 0 sets after crb (wave 1 reaches its sweep later than that, and polls it to be sure).
+      const int gen = 2 * s + pass + 1;                         // value of the "M ready" word for this pass
       if (wv == 0) kinematics<T, G>(c);
       __syncthreads();
-      if (wv == 0) { com_pos<T, G>(c); crb_factor<T, G>(c); }
+      if (wv == 0) com_pos<T, G>(c);
       else {
         collision<T, G>(c);
         if (lane == 0) { mail[0] = c.ncon; mail[2] = c.con_dropped; }
       }
       __syncthreads();
-      if (wv == 0) vel_bias_passive<T, G>(c);
-      else {
+      mjb_f16v invm;
+      if (wv == 0) {
+        crb_factor<T, G>(c);
+        gsync<G>();
+        if (lane == 0) __hip_atomic_store(mail + 5, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c.ncon = mail[0];
         make_constraint<T, G>(c);
         if (lane == 0) { mail[1] = c.nefc; mail[3] = c.efc_dropped; }
+      } else {
+        vel_bias_passive<T, G>(c);
+        while (__hip_atomic_load(mail + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen) __builtin_amdgcn_s_sleep(1);
+        invm = mfma_sweep_invert32<ModelRef<T>>(m, w + L.M, w + L.efc_J, w + L.efc_jv, 0, 0, nv, lane);
       }
       __syncthreads();
+      if (wv == 0) actuation_forces<T, G>(c);
+      __syncthreads();
+      if (wv == 1) mfma_sweep_apply32(invm, w + L.tmp, nv, lane, w + L.qacc_smooth);
+      __syncthreads();
       if (wv == 0) {
-        c.ncon = mail[0]; c.nefc = mail[1];
-        actuation_acceleration<T, G>(c);
+        c.nefc = mail[1];
         solve_constraints<T, G>(c);
         if (m.nsensor > 0) { sensors<T, T, G>(c, w + L.sens); gsync<G>(); }
         const bool bad = pass == 0 && group_bad<T, G>(w + L.qacc, nv, lane);
