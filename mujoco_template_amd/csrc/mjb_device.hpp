@@ -574,6 +574,14 @@ template <typename T> struct Ctx {
   MJB_DEVM Ctx(const DevModel<T> MJB_CONST* m_, const Lay MJB_CONST* L_, T* w_, int* wi_, int lane_) : mp(m_), lp(L_), w(w_), wi(wi_), lane(lane_), ncon(0), nefc(0), niter(0), con_dropped(0), efc_dropped(0) {}
 };
 
+// Diagnostic build -DMJB_PHASE_REPEAT: how many times an idempotent piece of the solver runs (ids 32.. name the pieces; 1 in the product)
+#if defined(MJB_PHASE_REPEAT) && !defined(MJB_HOST_EMU)
+#define MJB_REP_N(c, id) ((c).rep == (id) ? 2 : 1)
+#else
+#define MJB_REP_N(c, id) 1
+#endif
+enum { REP_CHOL = 32, REP_REUSE = 33, REP_MV = 34, REP_LS = 35, REP_WARM = 36, REP_GRAD = 37, REP_CTRL = 38 };
+
 // ---------------------------------------------------------------------------
 // Row-per-lane Cholesky in registers (G == 64, n <= 32): lane i keeps row i (padded to 32 with identity) in 32
 // VGPRs; a column step is one v_readlane + one FMA per trailing column — no LDS, no sync, no branches.
@@ -739,15 +747,22 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     // acc[4q+t] of lane (h, c) = A[8q+4h+t][c] = A[c][8q+4h+t] (symmetric): every lane reads along its own row of M,
     // so the 16 LDS reads use one address register and immediate offsets.  Rows/columns >= n are padded with identity.
     const int c = c_;
-    const float dadd = c < n ? (mode == 2 ? m.timestep * m.dof_damping[c] : 0.0f) : 1.0f;
-    const float* Mc = M + (c < n ? c : 0) * n + 4 * h;
-    const int nlim = c < n ? n - 4 * h : -1, rdiff = c - 4 * h;
+    const bool cin = c < n;
+    const float* Mc = M + (cin ? c : 0) * n + 4 * h;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      const int k = 8 * (i >> 2) + (i & 3);
-      float mv = Mc[k];                                        // may read past row c when 8q+4h+t >= n: masked
-      float v = k < nlim ? mv : 0.0f;
-      acc[i] = k == rdiff ? v + dadd : v;
+      const int k = 8 * (i >> 2) + (i & 3);                    // this register holds row k + 4 h
+      const float mv = Mc[k];                                  // may read past row c when the row is >= n: masked
+      // Round 3: one SHARED lane mask (c < n) for the registers whose rows exist in both halves (k + 4 < n: a uniform test, a
+      // compile-time one in the specialised kernel); only the last registers need the per-row test, and only they can hold the
+      // identity padding.  (The round-2 form built two lane masks per register - 32 SGPR pairs the compiler hoisted out of the step
+      // loop and kept spilled in VGPR lanes: two v_readlane + a hazard nop per use.)  Same values bit for bit.
+      float v;
+      if (k + 4 < n) v = cin ? mv : 0.0f;
+      else v = (cin && k + 4 * h < n) ? mv : 0.0f;
+      if (mode == 2) { if (k + 4 * h == c) v += cin ? m.timestep * m.dof_damping[c] : 1.0f; }      // + h D on the diagonal (identity on the padding)
+      else if (k + 4 >= n) { if (k + 4 * h == c && !cin) v += 1.0f; }                              // identity padding of rows / columns >= n
+      acc[i] = v;
     }
     if (mode == 1) {
       // Hessian M + J^T D J: one rank-2 MFMA per PAIR OF ACTIVE ROWS (D != 0), the next pair's J loads in flight
@@ -794,8 +809,10 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const 
     float d1 = __builtin_fmaxf(d - b * bia, Num<float>::minval());
     float inv1 = MJB_RSQF(d1);
     float v1 = v1r - bia * v0;
-    float L0 = c > j0 ? v0 * inv0 : (c == j0 ? a * inv0 : 0.0f);
-    float L1 = c > j1 ? v1 * inv1 : (c == j1 ? d1 * inv1 : 0.0f);
+    // lane j0 of v0 IS the pivot a (lane j1 of v1 is d1), so the diagonal needs no case of its own: one compare + select per column
+    // instead of two (bitwise the same unless a pivot fell below the 1e-15 clamp, which an SPD Hessian >= M never does)
+    float L0 = c >= j0 ? v0 * inv0 : 0.0f;
+    float L1 = c >= j1 ? v1 * inv1 : 0.0f;
     myinv = c == j0 ? inv0 : (c == j1 ? inv1 : myinv);
     // fused forward substitution
     float y0 = rdlane_f(r, j0) * inv0;
@@ -840,15 +857,22 @@ MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, con
     // acc[4q+t] of lane (h, c) = A[8q+4h+t][c] = A[c][8q+4h+t] (symmetric): every lane reads along its own row of M,
     // so the 16 LDS reads use one address register and immediate offsets.  Rows/columns >= n are padded with identity.
     const int c = c_;
-    const float dadd = c < n ? (mode == 2 ? m.timestep * m.dof_damping[c] : 0.0f) : 1.0f;
-    const float* Mc = M + (c < n ? c : 0) * n + 4 * h;
-    const int nlim = c < n ? n - 4 * h : -1, rdiff = c - 4 * h;
+    const bool cin = c < n;
+    const float* Mc = M + (cin ? c : 0) * n + 4 * h;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      const int k = 8 * (i >> 2) + (i & 3);
-      float mv = Mc[k];                                        // may read past row c when 8q+4h+t >= n: masked
-      float v = k < nlim ? mv : 0.0f;
-      acc[i] = k == rdiff ? v + dadd : v;
+      const int k = 8 * (i >> 2) + (i & 3);                    // this register holds row k + 4 h
+      const float mv = Mc[k];                                  // may read past row c when the row is >= n: masked
+      // Round 3: one SHARED lane mask (c < n) for the registers whose rows exist in both halves (k + 4 < n: a uniform test, a
+      // compile-time one in the specialised kernel); only the last registers need the per-row test, and only they can hold the
+      // identity padding.  (The round-2 form built two lane masks per register - 32 SGPR pairs the compiler hoisted out of the step
+      // loop and kept spilled in VGPR lanes: two v_readlane + a hazard nop per use.)  Same values bit for bit.
+      float v;
+      if (k + 4 < n) v = cin ? mv : 0.0f;
+      else v = (cin && k + 4 * h < n) ? mv : 0.0f;
+      if (mode == 2) { if (k + 4 * h == c) v += cin ? m.timestep * m.dof_damping[c] : 1.0f; }      // + h D on the diagonal (identity on the padding)
+      else if (k + 4 >= n) { if (k + 4 * h == c && !cin) v += 1.0f; }                              // identity padding of rows / columns >= n
+      acc[i] = v;
     }
     if (mode == 1) {
       // Hessian M + J^T D J: one rank-2 MFMA per PAIR OF ACTIVE ROWS (D != 0), the next pair's J loads in flight
@@ -2135,6 +2159,8 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
     dw[r] = act ? D[r] : (T)0;
   }
   T gpart = 0;
+  for (int rp_ = MJB_REP_N(c, REP_GRAD); rp_ > 0; rp_--) {
+  gpart = 0;
   if (jt_split<T, G>(nv)) {
     const int i = lane & 31;
     T jf = jt_dot<T, G>(J, force, nefc, nv, lane);
@@ -2146,6 +2172,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
       gpart += g * g;
     }
   }
+  }
   T gn = gsum<T, G>(gpart);
   const bool rebuild = (MJB_SWEEP_EXCLUDE != 1 && fused_inverse_path<T, G>(nv)) || gsumi<G>(chg) != 0;   // the sweep path keeps no factor
   gsync<G>();
@@ -2153,6 +2180,12 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
   c.pacc[PH_CNT_DIR] += 1; if (rebuild) c.pacc[PH_CNT_FACT] += 1;
 #endif
+  for (int rp_ = MJB_REP_N(c, rebuild ? REP_CHOL : REP_REUSE); rp_ > 1; rp_--) {      // diagnostic build: the solve twice, right-hand side restored
+    if (rebuild) factor_W<T, G>(c, 1, search);
+    else if (fused_inverse_path<T, G>(nv)) { gsync<G>(); mfma_solve32(W, w + L.tmp, search, nv, lane); }
+    for (int i = lane; i < nv; i += G) search[i] = grad[i];
+    gsync<G>();
+  }
   if (rebuild) factor_W<T, G>(c, 1, search);
   else if (fused_inverse_path<T, G>(nv)) { gsync<G>(); mfma_solve32(W, w + L.tmp, search, nv, lane); }
   else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
@@ -2179,7 +2212,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   // unconstrained point go to Ma / jar, those of the previous solution to Mv / jv (free until the first line search); the winner's
   // are then where the iterations expect them.  Per-row arithmetic and reduction order are those of solver_cost(): same costs, same decision.
   T cost;
-  {
+  for (int rp_ = MJB_REP_N(c, REP_WARM); rp_ > 0; rp_--) {
     T *aref = w + L.efc_aref;
     T pa = 0, pb = 0;
     const VecLds<T> xa{qas}, xb{ws};
@@ -2209,8 +2242,8 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
       if (wsw) jar[r] = sj;
       force[r] = sj < 0 ? -D[r] * sj : (T)0;
     }
+    gsync<G>();
   }
-  gsync<G>();
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
   for (int iter = 0; iter < MJB_OPT(c, iterations); iter++) {
     MJB_STAMP(c, PH_SOLVE);
@@ -2221,12 +2254,15 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
     const VecLds<T> xs{search};
+    for (int rp_ = MJB_REP_N(c, REP_MV); rp_ > 0; rp_--) {
+    p1 = 0; p2 = 0;
     for (int rho = lane; rho < nv + nefc; rho += G) {          // stacked [M; J] x search, one pass
       const bool ism = rho < nv;
       const int r = ism ? rho : rho - nv;
       T sacc = dot_lds(ism ? M + r * nv : J + r * nv, 1, xs, nv);
       if (ism) { Mv[r] = sacc; p1 += search[r] * (Ma[r] - qs[r]); p2 += search[r] * sacc; }
       else jv[r] = sacc;
+    }
     }
     T g1 = gsum<T, G>(p1), g2 = gsum<T, G>(p2);
     gsync<G>();
@@ -2237,7 +2273,8 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     // With nefc <= G every lane keeps its row (jar, jv, D jv) in registers: an iteration is a few VALU ops, two DPP
     // reductions and a ballot.
     T alpha = 0;
-    {
+    for (int rp_ = MJB_REP_N(c, REP_LS); rp_ > 0; rp_--) {
+      alpha = 0;
       const bool inreg = nefc <= G;
       T x0r = 0, jwr = 0, djr = 0;
       if (inreg && lane < nefc) { x0r = jar[lane]; jwr = jv[lane]; djr = D[lane] * jwr; }
@@ -2767,7 +2804,7 @@ MJB_DEV void env_run(const DevModel<T> MJB_CONST* mp, const Lay MJB_CONST* lp, D
       if (group_bad<T, G>(w + L.qpos, nq, lane)) { badqpos++; reset_state<T, G>(c); time = 0; }
       if (group_bad<T, G>(w + L.qvel, nv, lane)) { badqvel++; reset_state<T, G>(c); time = 0; }
       if (a.ctrl_mode == CTRL_RANDOM) {
-        random_ctrl<T, G>(m, w + L.ctrl, a.seed, a.env0 + (unsigned)env, a.step0 + (unsigned)s, (T)a.ctrl_scale, lane);
+        for (int rp_ = MJB_REP_N(c, REP_CTRL); rp_ > 0; rp_--) random_ctrl<T, G>(m, w + L.ctrl, a.seed, a.env0 + (unsigned)env, a.step0 + (unsigned)s, (T)a.ctrl_scale, lane);
         gsync<G>();
       } else if (a.ctrl_mode == CTRL_FEEDBACK) feedback_ctrl<T, G>(c, a, a.env0 + (unsigned)env, a.step0 + (unsigned)s);
     }

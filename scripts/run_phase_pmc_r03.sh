@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/${tag}
 mkdir -p $out
 W="python3 scripts/gpu_phase_pmc.py"
-for rep in -1 0 1 2 3 4 5 6 8; do
+for rep in ${REPS:--1 0 1 2 3 4 5 6 8}; do
   export MJB_REPEAT_PHASE=$rep
   n=rep${rep}
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${n}_kt -- $W > $out/${n}_kt.log 2>&1
