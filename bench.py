@@ -233,6 +233,7 @@ def main() -> None:
     weak_companion = None
     if distributed and not args.weak and ws > 1:
         wenv = make_env(args.global_batch * ws)
+        wenv._comm, wenv._collective = env._comm, env._collective      # one RCCL communicator per process: the companion gathers on the headline run's
         run(wenv, max(args.warmup, chunk))
         barrier()
         tw = time.perf_counter()
