@@ -12,6 +12,11 @@ K = int(sys.argv[sys.argv.index("--launches") + 1]) if "--launches" in sys.argv 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASES = {0: "kinematics (A1)", 1: "com_pos, cinert, cdof, tendons (A2/A3)", 3: "collision (A5)", 2: "crb -> M (A4)", 4: "constraint rows (A6)",
           5: "velocity stage: cvel, RNE bias, passive (A7)", 6: "actuation + M^-1 f (A8/A9)", 8: "Euler: (M + hD)^-1 solve (A11)"}
+# pieces of the Newton solver and of the step loop (REP_* repeat points of mjb_device.hpp; present when the set was run with them)
+SOLVER = {32: "  solver: Cholesky of H, factor + solve (all factorisations of the step)", 33: "  solver: solves that reuse the factor", 34: "  solver: [M; J] x search",
+          35: "  solver: line search", 36: "  solver: warm start (two cost evaluations)", 37: "  solver: gradient (J^T f)", 38: "  step loop: random ctrl (Philox)"}
+SOLVER_ORACLE = {32: ["solver: Cholesky + solve (A10)"], 33: [], 34: ["solver: M v, J v (A10)"], 35: ["solver: line search (A10)"], 36: ["solver: costs / warm start (A10)"],
+                 37: ["solver: gradient + Hessian assembly (A10)"], 38: []}
 # the oracle's phases that correspond to each device phase (profiles/r03_flops_per_env_step.json)
 ORACLE = {0: ["kinematics (A1)"], 1: ["com_pos (A2)", "tendon/transmission (A3)"], 3: ["collision (A5)"], 2: ["crb + factor M (A4)"], 4: ["constraint rows (A6)"],
           5: ["com_vel (A7)", "passive (A7)", "rne bias (A7)"], 6: ["actuation (A8)", "M^-1 f (A9)"], 8: ["integrator (A11)"]}
@@ -95,6 +100,17 @@ for rep, name in PHASES.items():
     for k, v in r.items():
         if isinstance(v, float) and k != "mean_active_lanes":
             acc[k] += v
+sub = []
+for rep, name in SOLVER.items():
+    if not os.path.isdir(os.path.join(src, f"rep{rep}_pmcA")):
+        continue
+    c = one(rep)
+    diff = {k: c.get(k, 0.0) - base.get(k, 0.0) for k in set(c) | set(base) if k != "ms"}
+    diff["ms"] = c["ms"] - base["ms"]
+    r = derive(diff)
+    r["phase"] = name
+    r["algorithmic_flops"] = sum(oracle.get(n, 0.0) for n in SOLVER_ORACLE[rep])
+    sub.append(r)
 rest = {k: whole[k] - acc[k] for k in whole if isinstance(whole[k], float) and k != "mean_active_lanes"}
 # active lanes of the remainder from the thread-cycle balance
 tc_rest = base.get("SQ_THREAD_CYCLES_VALU", 0.0) - sum((one(rep).get("SQ_THREAD_CYCLES_VALU", 0.0) - base.get("SQ_THREAD_CYCLES_VALU", 0.0)) for rep in PHASES)
@@ -110,15 +126,15 @@ out = [f"# per-phase hardware counters of mjb_k_step_spec (humanoid, B = 4096, 1
        "",
        f"{'phase':78s} {'us/launch':>9s} {'share':>6s} {'VALU':>7s} {'lanes':>6s} {'fp32 in':>8s} {'MFMA':>6s} {'exec flop':>10s} {'algo flop':>10s} {'useful':>7s}"]
 tot_ms = whole["ms_per_launch"]
-for r in rows + [dict(whole, phase="WHOLE KERNEL", algorithmic_flops=oracle_total)]:
+for r in rows + sub + [dict(whole, phase="WHOLE KERNEL", algorithmic_flops=oracle_total)]:
     ex = r["executed_valu_flops"] + r["executed_mfma_flops"]
     out.append(f"{r['phase']:78s} {1e3 * r['ms_per_launch']:9.1f} {100 * r['ms_per_launch'] / tot_ms:5.1f}% {r['valu_insts']:7.0f} {r['mean_active_lanes']:6.1f} {r['fp32_insts']:8.0f} "
                f"{r['mfma_mops_f32']:6.1f} {ex:10.0f} {r['algorithmic_flops']:10.0f} {r['algorithmic_flops'] / ex if ex else float('nan'):7.2f}")
-out += ["", "columns: us/launch = kernel-trace duration difference (409 600 env-steps per launch); VALU = wave-level VALU instructions; lanes = mean active lanes per VALU",
+out += ["", "(the indented rows are PART of the remainder row above them: pieces of the solver / step loop measured the same way)", "columns: us/launch = kernel-trace duration difference (409 600 env-steps per launch); VALU = wave-level VALU instructions; lanes = mean active lanes per VALU",
         "instruction; fp32 in = ADD + MUL + FMA + TRANS fp32 wave instructions; MFMA = SQ_INSTS_VALU_MFMA_MOPS_F32; exec flop = fp32 lane-flops actually executed",
         "(VALU classes x active lanes, FMA = 2, + 512 per MFMA MOP, padding included); algo flop = the oracle's count for the same phase; useful = algo / exec."]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_phase_table.txt"), "w").write("\n".join(out) + "\n")
-json.dump({"envsteps_per_launch": EPS, "launches": K, "full_lane_unit": unit, "whole_kernel": whole, "phases": rows, "raw_whole_kernel_counters": base,
+json.dump({"envsteps_per_launch": EPS, "launches": K, "full_lane_unit": unit, "whole_kernel": whole, "phases": rows, "solver_pieces": sub, "raw_whole_kernel_counters": base,
            "algorithmic_flops_per_env_step": oracle_total}, open(os.path.join(ROOT, "profiles", f"{tag}_phase_table.json"), "w"), indent=1)
 print("\n".join(out))
