@@ -663,6 +663,16 @@ MJB_DEV float half_bcast(float v, int half) {     // value of the given 32-lane 
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(half == 0 ? p[0] : p[1]);
 }
+// v_permlane32_swap: a' = [a.lo | b.lo], b' = [a.hi | b.hi] (lo = lanes 0..31, hi = lanes 32..63)
+MJB_DEV void half_swap(float a, float b, float& ao, float& bo) {
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  ao = __uint_as_float(p[0]); bo = __uint_as_float(p[1]);
+}
+// both 32-lane halves of v, each column-aligned in all 64 lanes, from ONE v_permlane32_swap (lo = lanes 0..31, hi = lanes 32..63)
+MJB_DEV void half_bcast2(float v, float& lo, float& hi) {
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  lo = __uint_as_float(p[0]); hi = __uint_as_float(p[1]);
+}
 // v(lane) + v(lane ^ 32): the sum over the two 32-lane halves, in all 64 lanes
 MJB_DEV float half_sum(float v) {
   auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -738,8 +748,120 @@ MJB_DEV void mfma_solve32(const float* W, const float* dinv, float* x, int n, in
   if (h == 0 && c_ < n) x[c_] = r;
   gsync<64>();
 }
+// ---- round 3: the accumulator in ELIMINATION ORDER -------------------------------------------------------------------------------
+// The hardware fixes which accumulator row a (register, half) pair holds: register 4q+t, half h <-> row 8q+4h+t.  Which MATRIX index
+// sits on accumulator row / column rho is ours to choose, as long as rows and columns use the same map (a symmetric relabelling).
+// With  pos(rho) = 8q + 2t + h  register i holds matrix rows 2i (lanes 0..31) and 2i+1 (lanes 32..63): the two pivot columns of panel
+// jb ARE register jb, already stacked the way the rank-2 MFMA wants its operands - no half broadcasts of two registers, no select.
+// Lane (h, c) stands for matrix column pos(c); everything the lanes index (rows of M, J, the packed factor) goes through pos(c) once,
+// outside the panel loop.  The factor that lands in LDS is the ordinary Cholesky factor in natural order (only lanes were relabelled).
+MJB_DEVM constexpr int acc_pos(int c) { return (c & 24) | ((c & 3) << 1) | ((c >> 2) & 1); }       // matrix index of accumulator row / column c
+MJB_DEVM constexpr int acc_lane(int p) { return (p & 24) | ((p & 1) << 2) | ((p >> 1) & 3); }      // its inverse
+// Second change: the right-hand side rides along as row / column n of the matrix (n < 32).  Cholesky of [A b; b^T 1] has y^T = (L^-1 b)^T
+// as row n of its factor, so the forward substitution IS the trailing update (the same MFMA) - no per-panel v_readlane / FMA / select
+// chain for it.  y is stored like any row of the factor (to ybuf) by the lane that stands for column n.
+// Third: nothing is masked on the way into the MFMA.  Columns already eliminated hold rounding residue instead of zeros; it only ever
+// feeds dead rows / columns (operand lane rho touches accumulator row rho, operand lane gamma column gamma).  Only the stores to LDS
+// are predicated.  The factor L is bitwise the one of the round-2 form (same pivots, same FMAs on the live entries).
 template <typename MRef>
-MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, float* ybuf, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c_ = lane & 31, pc = acc_pos(c_);
+  unsigned long long tq0 = pf ? MJB_MEMTIME() : 0;
+  const bool aug = x != nullptr && n < 32;                     // room for the right-hand side as column n
+  const bool cin = pc < n, isb = aug && pc == n;
+  mjb_f16v acc;
+  {
+    // acc[i] of lane (h, c) = A[2i+h][pos(c)] = A[pos(c)][2i+h]: every lane reads along its own row of M (the lane of column n along
+    // the right-hand side), one address register and immediate offsets.  Rows / columns beyond are padded with identity.
+    const float* Mc = (isb ? x : M + (cin ? pc : 0) * n) + h;
+    const float xv = (aug && cin) ? x[pc] : 0.0f;
+    const bool colok = cin || isb;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r0 = 2 * i;                                    // this register holds row r0 + h
+      const float mv = Mc[r0];                                 // may read past the row when r0 + h >= n: masked
+      float v;
+      if (r0 + 1 < n) v = colok ? mv : 0.0f;                   // both rows exist: one shared lane mask
+      else {
+        v = (colok && r0 + h < n) ? mv : 0.0f;
+        if (aug && r0 + h == n && cin) v = xv;                 // row n = the right-hand side
+      }
+      if (mode == 2) { if (r0 + h == pc) v += cin ? m.timestep * m.dof_damping[pc] : 1.0f; }       // + h D on the diagonal (identity on the padding)
+      else if (r0 + 1 >= n) { if (r0 + h == pc && !cin) v += 1.0f; }                               // identity padding of rows / columns >= n
+      acc[i] = v;
+    }
+    if (mode == 1) {
+      // Hessian M + J^T D J: one rank-2 MFMA per PAIR OF ACTIVE ROWS (D != 0), the next pair's J loads in flight
+      // while the current MFMA runs.
+      const int cm = cin ? pc : 0;
+      for (int base = 0; base < nefc; base += 64) {
+        const int rix = base + lane;
+        const float dl = rix < nefc ? dw[rix] : 0.0f;
+        unsigned long long act = MJB_BALLOT(dl != 0.0f);
+        float jcur = 0.0f, dcur = 0.0f;
+        bool have = false;
+        while (act) {
+          int ra = __builtin_ctzll(act); act &= act - 1;
+          int rb = ra; float dB = 0.0f;
+          if (act) { rb = __builtin_ctzll(act); act &= act - 1; dB = rdlane_f(dl, rb); }
+          float dA = rdlane_f(dl, ra);
+          int rr = h == 0 ? ra : rb;
+          float jn = J[(base + rr) * n + cm];
+          float dn = h == 0 ? dA : dB;
+          if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
+          jcur = cin ? jn : 0.0f; dcur = dn; have = true;
+        }
+        if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
+      }
+    }
+  }
+  float* const wrowp = (isb ? ybuf : W + tri_at(cin ? pc : 0, 0)) + h;     // lane (h, c) stores entry (pos(c), j0 + h): the column rides in the immediate offset
+  // lane (h, c) stores the entries (pos(c), j0 + h) with pos(c) >= j0 + h, up to the last stored row: ONE compare per panel against
+  // qs = pos(c) - h (lanes beyond the last stored row never pass)
+  int qs = pc <= (aug ? n : n - 1) ? pc - h : -64;
+  int dofs = 0;
+  MJB_OPAQUE1(dofs);                                          // dinv's address in a register for the whole loop (not re-materialised per panel)
+  float* const dinvp = dinv + dofs;
+  unsigned long long tq1 = pf ? MJB_MEMTIME() : 0;
+#pragma unroll
+  for (int jb = 0; jb < 16; jb++) {
+    const int j0 = 2 * jb, j1 = j0 + 1, l0 = acc_lane(j0), l1 = l0 + 4;
+    if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
+    MJB_OPAQUE1(qs);                              // keep the per-panel lane compares in the loop (cheaper than hoisted, spilled masks)
+    // S: columns j0 (lanes 0..31) and j1 (lanes 32..63) of the trailing matrix; the 2x2 pivot block [a b; b d] is eliminated in
+    // scalars so that the serial chain per panel is rsq -> fma -> rsq
+    const float S = acc[jb];
+    const float a = __builtin_fmaxf(rdlane_f(S, l0), Num<float>::minval()), b = rdlane_f(S, l1), d = rdlane_f(S, 32 + l1);
+    const float inv0 = MJB_RSQF(a), bia = b * inv0 * inv0;      // v_rsq_f32: 1 ulp, no refinement step on the chain
+    const float d1 = __builtin_fmaxf(d - b * bia, Num<float>::minval());
+    const float inv1 = j1 < n ? MJB_RSQF(d1) : 0.0f;           // n odd: the last panel has one real pivot
+    // lanes 0..31: L[.][j0] = v0 inv0;  lanes 32..63: L[.][j1] = (v1 - bia v0) inv1.  The half swap against a zero register hands the
+    // upper lanes both columns (z0 = [0 | v0], z1 = [0 | v1]) and clobbers S - rows j0, j1 are dead from here on - so the panel needs
+    // one swap and no copy of S; the lower lanes get their product before the swap, and (0 - bia 0) inv1 + x = x leaves it exact.
+    const float avlo = S * (h == 0 ? inv0 : 0.0f);
+    float z0, z1;
+    half_swap(0.0f, S, z0, z1);
+    acc[jb] = z1;
+    const float av = (z1 - bia * z0) * inv1 + avlo;
+    if (qs >= j0) wrowp[j0] = av;                               // packed factor (and y) to LDS for the backward substitution / later reuse
+    if (lane == 0) { dinvp[j0] = inv0; dinvp[j1] = inv1; }      // 1 / L_jj (uniform values: one lane, one ds_write2)
+    acc = MJB_MFMA(-av, av, acc);                               // rank-2 trailing update of the whole matrix
+  }
+  unsigned long long tq2 = pf ? MJB_MEMTIME() : 0;
+  gsync<64>();
+  if (x) {
+    if (aug) {                                                // backward substitution L^T x = y from the packed factor in LDS
+      const float r = c_ < n ? ybuf[c_] : 0.0f, myinv = c_ < n ? dinv[c_] : 1.0f;
+      float rs = mfma_backward32(W, n, c_, myinv, r);
+      if (h == 0 && c_ < n) x[c_] = rs;
+      gsync<64>();
+    } else mfma_solve32(W, dinv, x, n, lane);                  // n == 32: no spare column, both substitutions from LDS
+  }
+  if (pf) { unsigned long long tq3 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; pf[2] += tq3 - tq2; }
+}
+// the round-2 form (natural lane order, fused forward substitution in registers): kept for A/B runs (-DMJB_R2_FACTOR)
+template <typename MRef>
+MJB_DEV void mfma_factor32_r2(MRef m, const float* M, float* W, float* dinv, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
   const int h = lane >> 5, c_ = lane & 31;
   unsigned long long tq0 = pf ? MJB_MEMTIME() : 0;
   mjb_f16v acc;
@@ -984,7 +1106,9 @@ MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float
 template <typename MRef>
 MJB_DEV void mfma_sweep_solve32(MRef, const double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 template <typename MRef>
-MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
+MJB_DEV void mfma_factor32(MRef, const double*, double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
+template <typename MRef>
+MJB_DEV void mfma_factor32_r2(MRef, const double*, double*, double*, const double*, const double*, int, int, int, int, double*, unsigned long long* = nullptr) {}
 MJB_DEV void mfma_solve32(const double*, const double*, double*, int, int) {}
 
 // W <- Cholesky factor of M (mode 0), M + J^T D_active J (mode 1, dw in efc_jv) or M + h diag(damping) (mode 2)
@@ -1014,7 +1138,11 @@ template <typename T, int G> MJB_DEV void factor_W_impl(Ctx<T>& c, int mode, T* 
       unsigned long long* pf = nullptr;
 #endif
       if (sizeof(T) == 4 && mode != MJB_SWEEP_EXCLUDE) mfma_sweep_solve32<ModelRef<T>>(m, M, w + L.tmp, J, dw, nefc, mode, nv, lane, x, pf);
-      else if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x, pf);
+#ifdef MJB_R2_FACTOR
+      else if (sizeof(T) == 4) mfma_factor32_r2<ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x, pf);
+#else
+      else if (sizeof(T) == 4) mfma_factor32<ModelRef<T>>(m, M, W, w + L.tmp, w + L.cholcol, J, dw, nefc, mode, nv, lane, x, pf);
+#endif
       else reg_factor32<T, ModelRef<T>>(m, M, W, w + L.tmp, J, dw, nefc, mode, nv, lane, x);
       return;
     }

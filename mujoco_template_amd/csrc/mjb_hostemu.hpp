@@ -87,6 +87,21 @@ template <typename T> static inline T rdlane_f(T v, int l) {
 }
 static inline int rdlane_i(int v, int l) { return (int)rdlane_f<double>((double)v, l); }
 static inline float half_bcast(float v, int half) { return rdlane_f<float>(v, (emu::tl_lane & 31) + 32 * half); }
+static inline void half_swap(float a, float b, float& ao, float& bo) {           // v_permlane32_swap: a' = [a.lo | b.lo], b' = [a.hi | b.hi]
+  emu::Wave* w = emu::tl_wave; const int p = emu::next_phase();
+  w->a[p][emu::tl_lane] = a; w->b[p][emu::tl_lane] = b;
+  emu::sync();
+  const int l = emu::tl_lane, c = l & 31;
+  ao = l < 32 ? a : w->b[p][c];
+  bo = l < 32 ? w->a[p][c + 32] : b;
+}
+static inline void half_bcast2(float v, float& lo, float& hi) {
+  emu::Wave* w = emu::tl_wave; const int p = emu::next_phase();
+  w->f[p][emu::tl_lane] = (double)v;
+  emu::sync();
+  const int c = emu::tl_lane & 31;
+  lo = (float)w->f[p][c]; hi = (float)w->f[p][c + 32];
+}
 template <typename T> static inline T half_sum(T v) {
   emu::Wave* w = emu::tl_wave; const int p = emu::next_phase();
   w->f[p][emu::tl_lane] = (double)v;
