@@ -970,6 +970,96 @@ MJB_DEV void mfma_factor32_r2(MRef m, const float* M, float* W, float* dinv, con
 // is one register (+ a half swap) at every step.
 // Two halves, so that the two-wave step kernel (k_step2) can invert M + h D while the other wave still solves the constraints:
 // mfma_sweep_invert32 leaves -A^-1 in the accumulator, mfma_sweep_apply32 is the mat-vec.  mfma_sweep_solve32 = both.
+#ifndef MJB_R2_FACTOR
+// Round 3: the accumulator in elimination order (acc_pos above): the two pivot columns of panel jb are register jb, stacked
+// [u0 | u1] - which is the B operand U'^T itself once the two pivot lanes have had their 1 subtracted (and the register that goes on
+// living is that minus the same indicator again: the "-2" of the pivot diagonals).  One half swap hands every lane both columns for
+// the A operand.  acc = -A^-1 comes out in the same layout: register i, lane (h, c) = -A^-1[2i+h][pos(c)].
+template <typename MRef>
+MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, const float* dw, int nefc, int mode, int n, int lane, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c_ = lane & 31, pc = acc_pos(c_);
+  unsigned long long tq0 = pf ? MJB_MEMTIME() : 0;
+  const bool cin = pc < n;
+  mjb_f16v acc;
+  {
+    const float* Mc = M + (cin ? pc : 0) * n + h;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r0 = 2 * i;                                    // this register holds row r0 + h
+      const float mv = Mc[r0];                                 // may read past the row when r0 + h >= n: masked
+      float v;
+      if (r0 + 1 < n) v = cin ? mv : 0.0f;                     // both rows exist: one shared lane mask
+      else v = (cin && r0 + h < n) ? mv : 0.0f;
+      if (mode == 2) { if (r0 + h == pc) v += cin ? m.timestep * m.dof_damping[pc] : 1.0f; }       // + h D on the diagonal (identity on the padding)
+      else if (r0 + 1 >= n) { if (r0 + h == pc && !cin) v += 1.0f; }                               // identity padding of rows / columns >= n
+      acc[i] = v;
+    }
+    if (mode == 1) {
+      const int cm = cin ? pc : 0;
+      for (int base = 0; base < nefc; base += 64) {
+        const int rix = base + lane;
+        const float dl = rix < nefc ? dw[rix] : 0.0f;
+        unsigned long long act = MJB_BALLOT(dl != 0.0f);
+        float jcur = 0.0f, dcur = 0.0f;
+        bool have = false;
+        while (act) {
+          int ra = __builtin_ctzll(act); act &= act - 1;
+          int rb = ra; float dB = 0.0f;
+          if (act) { rb = __builtin_ctzll(act); act &= act - 1; dB = rdlane_f(dl, rb); }
+          float dA = rdlane_f(dl, ra);
+          int rr = h == 0 ? ra : rb;
+          float jn = J[(base + rr) * n + cm];
+          float dn = h == 0 ? dA : dB;
+          if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
+          jcur = cin ? jn : 0.0f; dcur = dn; have = true;
+        }
+        if (have) acc = MJB_MFMA(dcur * jcur, jcur, acc);
+      }
+    }
+  }
+  unsigned long long tq1 = pf ? MJB_MEMTIME() : 0;
+  int qs = pc - h;                                            // == j0 exactly on the two pivot lanes of a panel: (lower, column j0), (upper, column j1)
+#pragma unroll
+  for (int jb = 0; jb < 16; jb++) {
+    const int j0 = 2 * jb, l0 = acc_lane(j0), l1 = l0 + 4;
+    if (j0 >= n) continue;                                    // padded (identity) columns: nothing to eliminate (uniform skip)
+    MJB_OPAQUE1(qs);                              // keep the per-panel lane compare in the loop (cheaper than hoisted, spilled masks)
+    const float S = acc[jb];
+    const float a = __builtin_fmaxf(rdlane_f(S, l0), Num<float>::minval()), b = rdlane_f(S, l1), d = rdlane_f(S, 32 + l1);
+    const float det = __builtin_fmaxf(a * d - b * b, a * Num<float>::minval());
+    const float rdet = MJB_RCPF(det);
+    const float n00 = -d * rdet, n01 = b * rdet, n11 = -a * rdet;     // -P^-1: the A operand is -U' P^-1, the signs ride in the products
+    const float e = qs == j0 ? 1.0f : 0.0f;
+    const float bop = S - e;                                    // U'^T: [u0 - e_j0 | u1 - e_j1]
+    acc[jb] = bop - e;                                          // the -2 of the two pivot diagonals
+    float u0p, u1p;
+    half_bcast2(bop, u0p, u1p);
+    const float q0 = h == 0 ? n00 : n01, q1 = h == 0 ? n01 : n11;
+    const float aop = u0p * q0 + u1p * q1;
+    acc = MJB_MFMA(aop, bop, acc);
+  }
+  if (pf) { unsigned long long tq2 = MJB_MEMTIME(); pf[0] += tq1 - tq0; pf[1] += tq2 - tq1; }
+  return acc;
+}
+// x <- A^-1 x with acc = -A^-1 from mfma_sweep_invert32 (bpad: 32 words of LDS for the zero-padded right-hand side)
+MJB_DEV void mfma_sweep_apply32(const mjb_f16v& acc, float* bpad, int n, int lane, float* x, unsigned long long* pf = nullptr) {
+  const int h = lane >> 5, c_ = lane & 31, pc = acc_pos(c_);
+  unsigned long long tq2 = pf ? MJB_MEMTIME() : 0;
+  if (h == 0) bpad[c_] = c_ < n ? x[c_] : 0.0f;               // right-hand side, zero-padded to 32
+  gsync<64>();
+  {
+    const float* bp = bpad + h;                               // register i of half h multiplies b[2i + h]
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { s0 += acc[t] * bp[2 * t]; s1 += acc[4 + t] * bp[8 + 2 * t]; s2 += acc[8 + t] * bp[16 + 2 * t]; s3 += acc[12 + t] * bp[24 + 2 * t]; }
+    float s = (s0 + s1) + (s2 + s3);
+    float tot = half_sum(s);
+    if (h == 0 && pc < n) x[pc] = -tot;                       // acc = -A^-1
+    gsync<64>();
+  }
+  if (pf) pf[2] += MJB_MEMTIME() - tq2;
+}
+#else
 template <typename MRef>
 MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, const float* dw, int nefc, int mode, int n, int lane, unsigned long long* pf = nullptr) {
   const int h = lane >> 5, c_ = lane & 31;
@@ -1098,6 +1188,7 @@ MJB_DEV void mfma_sweep_apply32(const mjb_f16v& acc, float* bpad, int n, int lan
   }
   if (pf) pf[2] += MJB_MEMTIME() - tq2;
 }
+#endif
 template <typename MRef>
 MJB_DEV void mfma_sweep_solve32(MRef m, const float* M, float* bpad, const float* J, const float* dw, int nefc, int mode, int n, int lane, float* x, unsigned long long* pf = nullptr) {
   const mjb_f16v acc = mfma_sweep_invert32<MRef>(m, M, J, dw, nefc, mode, n, lane, pf);
