@@ -776,6 +776,12 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, float*
     const float* Mc = (isb ? x : M + (cin ? pc : 0) * n) + h;
     const float xv = (aug && cin) ? x[pc] : 0.0f;
     const bool colok = cin || isb;
+    // the lane's diagonal entry (row 2i + h == pos(c)) sits in ONE register, idg: + h D there (mode 2; identity on the padding), or the
+    // identity padding alone.  The damping is loaded ONCE, in front of the loop (inside it the compiler re-loaded it per register).
+    const int dq = pc - h, idiag = (dq & 1) ? -1 : dq >> 1;
+    const float hd = mode == 2 && cin ? m.timestep * m.dof_damping[pc] : 1.0f;
+    int idg = (mode == 2 || !cin) ? idiag : -1;
+    MJB_OPAQUE1(idg);                             // keep the sixteen compares here (hoisted out of the step loop they live as spilled lane masks)
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int r0 = 2 * i;                                    // this register holds row r0 + h
@@ -786,8 +792,7 @@ MJB_DEV void mfma_factor32(MRef m, const float* M, float* W, float* dinv, float*
         v = (colok && r0 + h < n) ? mv : 0.0f;
         if (aug && r0 + h == n && cin) v = xv;                 // row n = the right-hand side
       }
-      if (mode == 2) { if (r0 + h == pc) v += cin ? m.timestep * m.dof_damping[pc] : 1.0f; }       // + h D on the diagonal (identity on the padding)
-      else if (r0 + 1 >= n) { if (r0 + h == pc && !cin) v += 1.0f; }                               // identity padding of rows / columns >= n
+      if (mode == 2 || r0 + 1 >= n) v += i == idg ? hd : 0.0f;
       acc[i] = v;
     }
     if (mode == 1) {
@@ -983,6 +988,13 @@ MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, con
   mjb_f16v acc;
   {
     const float* Mc = M + (cin ? pc : 0) * n + h;
+    // the lane's diagonal entry (row 2i + h == pos(c)) sits in ONE register, idg: + h D there (mode 2; identity on the padding), or the
+    // identity padding alone.  The damping is loaded ONCE, in front of the loop: inside it the compiler re-loaded it per register -
+    // sixteen dependent global loads in a row, which made the Euler solve the slowest 470 instructions of the step.
+    const int dq = pc - h, idiag = (dq & 1) ? -1 : dq >> 1;
+    const float hd = mode == 2 && cin ? m.timestep * m.dof_damping[pc] : 1.0f;
+    int idg = (mode == 2 || !cin) ? idiag : -1;
+    MJB_OPAQUE1(idg);                             // keep the sixteen compares here (hoisted out of the step loop they live as spilled lane masks)
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int r0 = 2 * i;                                    // this register holds row r0 + h
@@ -990,8 +1002,7 @@ MJB_DEV mjb_f16v mfma_sweep_invert32(MRef m, const float* M, const float* J, con
       float v;
       if (r0 + 1 < n) v = cin ? mv : 0.0f;                     // both rows exist: one shared lane mask
       else v = (cin && r0 + h < n) ? mv : 0.0f;
-      if (mode == 2) { if (r0 + h == pc) v += cin ? m.timestep * m.dof_damping[pc] : 1.0f; }       // + h D on the diagonal (identity on the padding)
-      else if (r0 + 1 >= n) { if (r0 + h == pc && !cin) v += 1.0f; }                               // identity padding of rows / columns >= n
+      if (mode == 2 || r0 + 1 >= n) v += i == idg ? hd : 0.0f;
       acc[i] = v;
     }
     if (mode == 1) {
