@@ -1344,7 +1344,8 @@ template <typename T, int G, int NC> MJB_DEV void tree_forward_sum(Ctx<T>& c, T*
     s[ps] = 0;
     if (e < nitem) {
       const int b = e / NC, k = e - b * NC;
-      const int na = b > 0 ? m.body_depth[b] - 1 : 0;
+      int na = b > 0 ? m.body_depth[b] - 1 : 0;
+      MJB_OPAQUE1(na);                            // lane constants: compared here (one v_cmp each), not hoisted out of the step loop as spilled lane masks
       T acc = arr[e];
       for (int u = 0; u < nl - 1; u++) {
         const int a = m.body_anc[b * nl + u];
@@ -1370,7 +1371,8 @@ template <typename T, int G, int NC> MJB_DEV void tree_backward_sum(Ctx<T>& c, T
     s[ps] = 0;
     if (e < nitem) {
       const int b = e / NC;
-      const int n = b >= first_body ? m.body_nsub[b] : 0;
+      int n = b >= first_body ? m.body_nsub[b] : 0;
+      MJB_OPAQUE1(n);                             // as above
       const T* base = arr + e;
       T acc = base[0];
       for (int d0 = 0; d0 < mx; d0 += 4) {                      // four masked loads in flight per step
