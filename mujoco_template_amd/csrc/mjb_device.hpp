@@ -82,12 +82,23 @@ MJB_DEV float rdlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_
 MJB_DEV double rdlane_f(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+// The four row totals of a wavefront combined with the two wave-level DPP broadcasts of gfx9 (row_bcast:15 into rows 1 and 3, then
+// row_bcast:31 into rows 2 and 3: lane 63 ends with (r0 + r1) + (r2 + r3)) and ONE v_readlane - instead of four v_readlane and three
+// scalar-operand adds.  Same association as the readlane form, so the sums are bitwise the same.  As inline assembly: the compiler
+// does not fold a partial row mask into the add (it emits a zero, a v_mov_dpp and the add); the s_nop 1 are the two wait states a
+// DPP read needs after the VALU write of its source.  float only (the float64 / integer forms keep the readlanes: not on the hot path).
+MJB_DEV float wave_rows_sum(float v) {
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return rdlane_f(v, 63);
+}
+MJB_DEV double wave_rows_sum(double v) { return (rdlane_f(v, 0) + rdlane_f(v, 16)) + (rdlane_f(v, 32) + rdlane_f(v, 48)); }
+MJB_DEV int wave_rows_sum(int v) { return (rdlane_i(v, 0) + rdlane_i(v, 16)) + (rdlane_i(v, 32) + rdlane_i(v, 48)); }
 template <typename T, int G> MJB_DEV T gsum(T v) {
   v += dpp_f<0xB1>(v);
   v += dpp_f<0x4E>(v);
   if (G >= 8) v += dpp_f<0x141>(v);
   if (G >= 16) v += dpp_f<0x140>(v);
-  if (G == 64) v = (rdlane_f(v, 0) + rdlane_f(v, 16)) + (rdlane_f(v, 32) + rdlane_f(v, 48));
+  if (G == 64) v = wave_rows_sum(v);
   return v;
 }
 template <int G> MJB_DEV int gsumi(int v) {
@@ -95,7 +106,7 @@ template <int G> MJB_DEV int gsumi(int v) {
   v += dpp_i<0x4E>(v);
   if (G >= 8) v += dpp_i<0x141>(v);
   if (G >= 16) v += dpp_i<0x140>(v);
-  if (G == 64) v = (rdlane_i(v, 0) + rdlane_i(v, 16)) + (rdlane_i(v, 32) + rdlane_i(v, 48));
+  if (G == 64) v = wave_rows_sum(v);
   return v;
 }
 template <int G> MJB_DEV int gmaxi(int v) {
