@@ -1378,23 +1378,24 @@ template <typename T, int G, int NC> MJB_DEV void tree_backward_sum(Ctx<T>& c, T
   T s[MJB_TREE_PASSES];
 #pragma unroll
   for (int ps = 0; ps < MJB_TREE_PASSES; ps++) {
+    if (ps * G >= nitem) { s[ps] = 0; continue; }             // (uniform) no item in this pass
     const int e = lane + ps * G;
-    s[ps] = 0;
-    if (e < nitem) {
-      const int b = e / NC;
-      int n = b >= first_body ? m.body_nsub[b] : 0;
-      MJB_OPAQUE1(n);                             // as above
-      const T* base = arr + e;
-      T acc = base[0];
-      for (int d0 = 0; d0 < mx; d0 += 4) {                      // four masked loads in flight per step
-        T v[4];
+    const bool on = e < nitem;
+    const int b = on ? e / NC : 0;
+    const int n = on && b >= first_body ? m.body_nsub[b] : 0;
+    const T* base = arr + (on ? e : 0);
+    T acc = base[0];
+    // four masked loads in flight per step - for as long as ANY item of this pass has descendants left: the bodies are in depth-first
+    // order, so the long subtrees (torso, waist) sit in the first pass and the later passes stop after one step (humanoid, 10
+    // components: 4 + 1 + 1 steps instead of 3 x 4)
+    for (int d0 = 0; d0 < mx && gany<G>(d0 < n); d0 += 4) {
+      T v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int dd = d0 + u + 1; v[u] = base[NC * (dd <= n ? dd : n)]; }
+      for (int u = 0; u < 4; u++) { const int dd = d0 + u + 1; v[u] = base[NC * (dd <= n ? dd : n)]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc += d0 + u + 1 <= n ? v[u] : (T)0;
-      }
-      s[ps] = acc;
+      for (int u = 0; u < 4; u++) acc += d0 + u + 1 <= n ? v[u] : (T)0;
     }
+    s[ps] = acc;
   }
   gsync<G>();
 #pragma unroll

@@ -4,6 +4,7 @@
 // kernel source (lane-strided loops, scans, shuffles, syncs) without a GPU.
 // Never part of the product library: the product fails loudly without a HIP device.
 #pragma once
+#include <cstring>
 #include <pthread.h>
 
 #include <cmath>
@@ -87,6 +88,8 @@ template <typename T> static inline T rdlane_f(T v, int l) {
 }
 static inline int rdlane_i(int v, int l) { return (int)rdlane_f<double>((double)v, l); }
 static inline float half_bcast(float v, int half) { return rdlane_f<float>(v, (emu::tl_lane & 31) + 32 * half); }
+static inline unsigned __float_as_uint(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float x; std::memcpy(&x, &u, 4); return x; }
 static inline void half_swap(float a, float b, float& ao, float& bo) {           // v_permlane32_swap: a' = [a.lo | b.lo], b' = [a.hi | b.hi]
   emu::Wave* w = emu::tl_wave; const int p = emu::next_phase();
   w->a[p][emu::tl_lane] = a; w->b[p][emu::tl_lane] = b;
