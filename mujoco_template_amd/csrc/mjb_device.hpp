@@ -1442,13 +1442,13 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
       for (int k = 0; k < 3; k++) pos[k] = m.body_pos[3 * b + k];
 #pragma unroll
       for (int k = 0; k < 4; k++) quat[k] = m.body_quat[4 * b + k];
+      quat2mat(R, quat);                                       // R follows quat through the joints: formed once per change, not twice
       for (int j = jadr; j < jadr + jnum; j++) {
         T jp[3] = {m.jnt_rec[8 * j], m.jnt_rec[8 * j + 1], m.jnt_rec[8 * j + 2]};
         T ja[3] = {m.jnt_rec[8 * j + 3], m.jnt_rec[8 * j + 4], m.jnt_rec[8 * j + 5]};
         const int jtype = m.jnt_irec[6 * j], qa = m.jnt_irec[6 * j + 1];
         T val = qpos[qa] - m.jnt_rec[8 * j + 6];
         T anchor[3], axis[3];
-        quat2mat(R, quat);
         mulmatvec3(anchor, R, jp);
         anchor[0] += pos[0]; anchor[1] += pos[1]; anchor[2] += pos[2];
         mulmatvec3(axis, R, ja);
@@ -1461,7 +1461,8 @@ template <typename T, int G> MJB_DEV void kinematics(Ctx<T>& c) {
           axisangle2quat(ql, ja, val);
           quat_mul(qn, quat, ql);
           quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-          quat_rot(v, quat, jp);
+          quat2mat(R, quat);                                   // = quat_rot(v, quat, jp), keeping the matrix for the next joint
+          mulmatvec3(v, R, jp);
           pos[0] = anchor[0] - v[0]; pos[1] = anchor[1] - v[1]; pos[2] = anchor[2] - v[2];
         }
       }
