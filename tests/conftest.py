@@ -39,6 +39,27 @@ BASE_XML = """
 """
 
 
+def chain_xml(n, link=0.1, z0=0.3):
+    """A synthetic n-link chain (hinges about alternating axes, capsule links over a floor, a motor on every fourth joint): nv = n.  Not a
+    reference model - it exists to run the fp32 MFMA solves (one wavefront per environment, nv <= 32) at matrix sizes the reference's
+    models do not have: n = 32 (no spare column for the right-hand side), even n, n far below 32."""
+    s = ['<mujoco model="chain"><option timestep="0.005"/>',
+         '<default><joint type="hinge" armature="0.3" damping="0.3" limited="true" range="-50 50"/>',
+         '<geom type="capsule" size="0.03" contype="1" conaffinity="0" density="800"/></default>',
+         '<worldbody><geom name="floor" type="plane" size="5 5 0.1" contype="1" conaffinity="1"/>']
+    for k in range(n):
+        pos = f"0 0 {z0}" if k == 0 else f"{link} 0 0"
+        ax = "0 1 0" if k % 2 == 0 else "0 0 1"
+        ct = 1 if k >= n - 4 else 0                                # only the last four links collide with the floor: at most 8 contacts
+        s.append(f'<body name="b{k}" pos="{pos}"><joint name="j{k}" axis="{ax}"/><geom fromto="0 0 0 {link} 0 0" contype="{ct}"/>')
+    s.append("</body>" * n)
+    s.append("</worldbody><actuator>")
+    for k in range(0, n, 4):
+        s.append(f'<motor name="m{k}" joint="j{k}" gear="2" ctrllimited="true" ctrlrange="-1 1"/>')
+    s.append("</actuator></mujoco>")
+    return "\n".join(s)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

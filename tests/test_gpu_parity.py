@@ -206,6 +206,52 @@ def test_float64_free_running_matches_oracle(world, name, steps):
     assert cn["efc_dropped"].sum() == 0 and cn["con_dropped"].sum() == 0
 
 
+CHAIN_TOL32 = {32: (3.7e-4, 2.0e-6, 3.9e-4), 31: (2.7e-4, 9.8e-7, 2.0e-4), 30: (2.4e-4, 6.4e-7, 1.3e-4), 17: (2.8e-5, 7.6e-8, 5.2e-6), 6: (4.9e-5, 1.5e-7, 3.8e-6)}     # (qacc rel, dqpos, dqvel rel) = 3x measured
+
+
+@pytest.mark.parametrize("n", [32, 31, 30, 17, 6])
+def test_fp32_mfma_solves_at_other_matrix_sizes(n):
+    """The fp32 hot path of one wavefront per environment (nv <= 32: sweep inverse of M and M + hD, MFMA Cholesky of the Newton Hessian in
+    the elimination-order accumulator) at matrix sizes the reference's models do not have - synthetic chains (tests.conftest.chain_xml)
+    with floor contacts and joint limits: n = 32 (no spare column: the right-hand side cannot ride along, both substitutions come from
+    the packed factor), n = 31 / 17 (odd: a half panel at the end), n = 30 (even), n = 6 with the 64-lane layout forced.  Teacher-forced
+    along the float64 oracle's trajectory under random ctrl; also bitwise equal between the specialised and the generic kernel."""
+    from tests.conftest import chain_xml
+    cm = mjcf.compile_xml_string(chain_xml(n))
+    om, dm = mjo.OracleModel(cm), DeviceModel(cm)
+    B = 8
+    sim = BatchSim(dm, B, dtype="float32", lanes=64, nconmax=16, nefcmax=72)         # explicit caps: the automatic ones trade rows for eight environments per CU
+    gen = BatchSim(dm, B, dtype="float32", lanes=64, nconmax=16, nefcmax=72, specialize=False)
+    assert sim.lanes == 64
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    rng = np.random.default_rng(n)
+    for od in ods:
+        od.qpos[:] = rng.normal(size=cm.nq) * 0.02
+        od.qpos[0] += np.arcsin(min(0.99, 0.3 / (0.1 * n)))               # pitched down until the tip touches the floor
+        od.qvel[:] = rng.normal(size=cm.nv) * 0.1
+    worst_a = worst_q = worst_v = 0.0
+    rows = 0
+    for s in range(30):
+        u = np.stack([od.random_ctrl(5, e, s, 1.0) for e, od in enumerate(ods)])
+        for x in (sim, gen):
+            x.set("qpos", np.stack([od.qpos for od in ods])); x.set("qvel", np.stack([od.qvel for od in ods]))
+            x.set("qacc_warmstart", np.stack([od.qacc_warmstart for od in ods])); x.set("ctrl", u)
+            x.step(1)
+        for e, od in enumerate(ods):
+            od.ctrl[:] = u[e]; od.step()
+        rows = max(rows, max(od.counters()["nefc"] for od in ods))
+        ao, qo, vo = np.stack([od.qacc for od in ods]), np.stack([od.qpos for od in ods]), np.stack([od.qvel for od in ods])
+        worst_a = max(worst_a, np.abs(sim.get("qacc") - ao).max() / max(1.0, np.abs(ao).max()))
+        worst_q = max(worst_q, np.abs(sim.get("qpos") - qo).max())
+        worst_v = max(worst_v, (np.abs(sim.get("qvel") - vo) / np.maximum(1.0, np.abs(vo))).max())
+        assert np.array_equal(sim.get("qpos"), gen.get("qpos")) and np.array_equal(sim.get("qacc"), gen.get("qacc"))
+    assert rows >= (8 if n >= 17 else 4)                                  # the Hessian path was taken
+    assert sim.counters()["efc_dropped"].sum() == 0 and sim.counters()["con_dropped"].sum() == 0
+    measured(f"mfma_sizes/chain{n}/qacc_rel", worst_a, CHAIN_TOL32[n][0])
+    measured(f"mfma_sizes/chain{n}/qpos", worst_q, CHAIN_TOL32[n][1])
+    measured(f"mfma_sizes/chain{n}/qvel_rel", worst_v, CHAIN_TOL32[n][2])
+
+
 @pytest.mark.parametrize("name,steps", [("pendulum", 100), ("cartpole", 100), ("drone2", 100), ("humanoid", 100), ("base", 100)])
 def test_fp32_teacher_forced_single_step(world, name, steps):
     """fp32 product path from identical states (teacher-forced along the oracle trajectory): one-step |dqpos| and

@@ -205,3 +205,28 @@ def test_fp32_mfma_solver_paths_run_on_the_cpu(compiled):
         od.ctrl[:] = u; e.ctrl[:cm.nu] = u
         od.step(); e.step()
     assert np.abs(e.qpos - od.qpos).max() < 2e-5
+
+
+@pytest.mark.parametrize("n", [32, 30])
+def test_fp32_mfma_solves_at_other_matrix_sizes_on_the_cpu(n):
+    """The elimination-order MFMA Cholesky / sweep inverse at sizes the reference's models do not have (tests.conftest.chain_xml): n = 32
+    has no spare accumulator column for the right-hand side (both substitutions come from the packed factor instead), n = 30 is even
+    (no half panel at the end).  Emulated wave intrinsics against the float64 oracle, teacher-forced, contacts and limits active."""
+    from tests.conftest import chain_xml
+    from mujoco_template_amd import mjcf
+    cm = mjcf.compile_xml_string(chain_xml(n))
+    od = mjo.OracleData(mjo.OracleModel(cm))
+    e = EmuEnv(cm, G=64, use_double=False, ncon_max=16, nefc_max=48)
+    od.qpos[:] = 0; od.qpos[0] = np.arcsin(0.3 / (0.1 * n))              # pitched down until the tip touches the floor
+    worst = 0.0
+    for s in range(3):
+        u = od.random_ctrl(1, 0, s, 1.0)
+        e.qpos[:] = od.qpos; e.qvel[:] = od.qvel; e.qacc_warmstart[:] = od.qacc_warmstart; e.ctrl[:cm.nu] = u
+        od.ctrl[:] = u
+        od.forward(); e.forward()
+        assert e.counters[1] == od.counters()["nefc"] >= 8
+        worst = max(worst, np.abs(e.qacc - od.qacc).max() / max(1.0, np.abs(od.qacc).max()),
+                    np.abs(e.qacc_smooth - od.qacc_smooth).max() / max(1.0, np.abs(od.qacc_smooth).max()))
+        od.step(); e.step()
+        assert np.abs(e.qpos - od.qpos).max() < 2e-7 and np.abs(e.qvel - od.qvel).max() < 4e-5
+    assert worst < 6e-4                                                  # measured 1.4e-4 (n = 32), 8.5e-5 (n = 30)
