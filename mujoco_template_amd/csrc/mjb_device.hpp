@@ -2388,21 +2388,24 @@ template <typename T, int G> MJB_DEV T solver_cost(Ctx<T>& c, const T* qacc, boo
   return cost;
 }
 
-template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T gtol2) {
+// Active set of one constraint row at its new residual sj: bit 8 of efc_type remembers the state the last factor was built with,
+// dw (kept in the jv array, free between the line search and the next [M; J] x search) = D on active rows.  Returns whether the row
+// changed state.  Called by the loops that PRODUCE the residual (warm start, update) - the row's lane has sj and D in registers there,
+// so the scan costs no pass of its own over jar / D.
+template <typename T> MJB_DEV bool mark_active_row(int* etype, T* dw, int r, T sj, T d) {
+  const int act = sj < 0 ? 1 : 0, t = etype[r];
+  etype[r] = (t & ~0x100) | (act << 8);
+  dw[r] = act ? d : (T)0;
+  return ((t >> 8) & 1) != act;
+}
+template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool rebuild_wanted, T gtol2) {
   // grad, H = M + J^T D_active J (lower, Cholesky in W), search = -H^-1 grad.  Returns |grad|^2; when that is
   // already below gtol2 the (expensive) factorisation is skipped — the caller stops iterating.
-  // The factor is rebuilt only when the active set changed since the last build (bit 8 of efc_type remembers it).
+  // The factor is rebuilt only when the active set changed since the last build (rebuild_wanted: first direction of the solve, or a row
+  // changed state in the update that produced the current point - mark_active_row).
   MJB_ENV(c); T* w = c.w; const int lane = c.lane, nv = m.nv, nefc = c.nefc;
-  T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *D = w + L.efc_D, *force = w + L.efc_force;
-  T *grad = w + L.grad, *search = w + L.search, *qs = w + L.qfrc_smooth, *dw = w + L.efc_jv;
-  int* etype = c.wi + L.i_efc_type;
-  int chg = first ? 1 : 0;
-  for (int r = lane; r < nefc; r += G) {
-    int act = jar[r] < 0 ? 1 : 0, t = etype[r];
-    if (((t >> 8) & 1) != act) chg = 1;
-    etype[r] = (t & ~0x100) | (act << 8);
-    dw[r] = act ? D[r] : (T)0;
-  }
+  T *M = w + L.M, *W = w + L.W, *J = w + L.efc_J, *Ma = w + L.Ma, *force = w + L.efc_force;
+  T *grad = w + L.grad, *search = w + L.search, *qs = w + L.qfrc_smooth;
   T gpart = 0;
   for (int rp_ = MJB_REP_N(c, REP_GRAD); rp_ > 0; rp_--) {
   gpart = 0;
@@ -2419,7 +2422,7 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool first, T
   }
   }
   T gn = gsum<T, G>(gpart);
-  const bool rebuild = (MJB_SWEEP_EXCLUDE != 1 && fused_inverse_path<T, G>(nv)) || gsumi<G>(chg) != 0;   // the sweep path keeps no factor
+  const bool rebuild = (MJB_SWEEP_EXCLUDE != 1 && fused_inverse_path<T, G>(nv)) || rebuild_wanted;   // the sweep path keeps no factor
   gsync<G>();
   if (gn < gtol2) return gn;
 #if defined(MJB_PROFILE) && !defined(MJB_HOST_EMU)
@@ -2450,6 +2453,7 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
   }
   T *M = w + L.M, *J = w + L.efc_J, *Ma = w + L.Ma, *jar = w + L.efc_jar, *jv = w + L.efc_jv, *D = w + L.efc_D, *force = w + L.efc_force;
   T *search = w + L.search, *Mv = w + L.Mv, *qs = w + L.qfrc_smooth;
+  int* etype = c.wi + L.i_efc_type;
   // warmstart(): best of (qacc_warmstart, qacc_smooth) as the starting point.  The unconstrained point is evaluated FIRST so
   // that in the common case (the warm start wins) Ma / jar / force are already those of the chosen point: two cost
   // evaluations instead of three; same costs, same decision (warm start only if strictly cheaper).
@@ -2483,19 +2487,24 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
     cost = wsw ? cost_b : cost_a;
     for (int i = lane; i < nv; i += G) { qacc[i] = wsw ? ws[i] : qas[i]; if (wsw) Ma[i] = Mv[i]; }
     for (int r = lane; r < nefc; r += G) {
-      const T sj = wsw ? jv[r] : jar[r];
+      const T sj = wsw ? jv[r] : jar[r], d = D[r];
       if (wsw) jar[r] = sj;
-      force[r] = sj < 0 ? -D[r] * sj : (T)0;
+      force[r] = sj < 0 ? -d * sj : (T)0;
+      mark_active_row<T>(etype, jv, r, sj, d);                   // (jv's candidate residual has been read: the array is free for dw)
     }
     gsync<G>();
   }
+  bool rebuild_wanted = true;                                    // first direction of the solve
   const T scale = 1 / (m.meaninertia * (T)(nv > 1 ? nv : 1));
-  for (int iter = 0; iter < MJB_OPT(c, iterations); iter++) {
+  // the run-time options are read ONCE per solve (they sit in device memory behind c.mp: inside the loop every iteration paid the
+  // scalar loads again - the group syncs are fences - and a division for the gradient tolerance)
+  const int max_iter = MJB_OPT(c, iterations);
+  const T tolerance = MJB_OPT(c, tolerance), gtol = tolerance / scale, gtol2 = gtol * gtol;
+  for (int iter = 0; iter < max_iter; iter++) {
     MJB_STAMP(c, PH_SOLVE);
-    const T gtol = MJB_OPT(c, tolerance) / scale;
-    T gn = newton_direction<T, G>(c, iter == 0, gtol * gtol);
+    T gn = newton_direction<T, G>(c, rebuild_wanted, gtol2);
     MJB_STAMP(c, PH_SOL_DIR);
-    if (gn < gtol * gtol) break;
+    if (gn < gtol2) break;
     // Mv, jv and the Gauss part of the 1-D quadratic
     T p1 = 0, p2 = 0;
     const VecLds<T> xs{search};
@@ -2563,16 +2572,19 @@ template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
       qacc[i] = a; Ma[i] = ma;
       part += (T)0.5 * (ma - qs[i]) * (a - qas[i]);
     }
+    bool chg = false;
     for (int r = lane; r < nefc; r += G) {
-      T sj = jar[r] + alpha * jv[r];
+      const T sj = jar[r] + alpha * jv[r], d = D[r];
       jar[r] = sj;
-      if (sj < 0) { part += (T)0.5 * D[r] * sj * sj; force[r] = -D[r] * sj; } else force[r] = 0;
+      if (sj < 0) { part += (T)0.5 * d * sj * sj; force[r] = -d * sj; } else force[r] = 0;
+      chg = mark_active_row<T>(etype, jv, r, sj, d) || chg;      // the next direction's active set, while sj and D are in registers
     }
     T old = cost;
     cost = gsum<T, G>(part);
+    rebuild_wanted = gany<G>(chg);
     gsync<G>();
     c.niter = iter + 1;
-    if (scale * (old - cost) < MJB_OPT(c, tolerance)) break;
+    if (scale * (old - cost) < tolerance) break;
   }
   if (jt_split<T, G>(nv)) {
     T jf = jt_dot<T, G>(J, force, nefc, nv, lane);
