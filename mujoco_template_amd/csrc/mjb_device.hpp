@@ -2412,11 +2412,11 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool rebuild_
   if (jt_split<T, G>(nv)) {
     const int i = lane & 31;
     T jf = jt_dot<T, G>(J, force, nefc, nv, lane);
-    if (lane < nv) { T g = Ma[i] - qs[i] - jf; grad[i] = g; search[i] = g; gpart = g * g; }
+    if (lane < nv) { T g = Ma[i] - qs[i] - jf; grad[i] = g; search[i] = -g; gpart = g * g; }      // right-hand side -g: the solve returns the search direction itself
   } else {
     for (int i = lane; i < nv; i += G) {
       T g = Ma[i] - qs[i] - dot_lds(J + i, nv, VecLds<T>{force}, nefc);
-      grad[i] = g; search[i] = g;
+      grad[i] = g; search[i] = -g;
       gpart += g * g;
     }
   }
@@ -2431,15 +2431,13 @@ template <typename T, int G> MJB_DEV T newton_direction(Ctx<T>& c, bool rebuild_
   for (int rp_ = MJB_REP_N(c, rebuild ? REP_CHOL : REP_REUSE); rp_ > 1; rp_--) {      // diagnostic build: the solve twice, right-hand side restored
     if (rebuild) factor_W<T, G>(c, 1, search);
     else if (fused_inverse_path<T, G>(nv)) { gsync<G>(); mfma_solve32(W, w + L.tmp, search, nv, lane); }
-    for (int i = lane; i < nv; i += G) search[i] = grad[i];
+    for (int i = lane; i < nv; i += G) search[i] = -grad[i];
     gsync<G>();
   }
   if (rebuild) factor_W<T, G>(c, 1, search);
   else if (fused_inverse_path<T, G>(nv)) { gsync<G>(); mfma_solve32(W, w + L.tmp, search, nv, lane); }
   else chol_solve<T, G>(W, w + L.tmp, search, nv, lane);
-  for (int i = lane; i < nv; i += G) search[i] = -search[i];
-  gsync<G>();
-  return gn;
+  return gn;                                                   // (every solve ends with a group sync; H x = -g, so x is the direction: no negation pass)
 }
 
 template <typename T, int G> MJB_DEV void solve_constraints(Ctx<T>& c) {
