@@ -429,6 +429,16 @@ std::string spec_source(const HostModel& h, const Lay& L, int G, int ncon_max, i
 #undef SL
   s += "\n";
   {
+    // solimp powers of the model (joint limits, tendon limits, contact pairs): when every one is 1 or 2 (2 is MuJoCo's default) the
+    // impedance curve needs no powf, and the specialised kernel is compiled without that code (~2 000 instructions of a cold branch)
+    bool le2 = true;
+    for (const char* name : {"jnt_solimp", "tendon_solimp", "pair_solimp"}) {
+      const auto& v = h.D(name);
+      for (size_t k = 4; k < v.size(); k += 5) { const double pw = v[k] > 1.0 ? v[k] : 1.0; if (pw != 1.0 && pw != 2.0) le2 = false; }
+    }
+    if (le2) s += "#define MJB_SPEC_SOLIMP_POWER_1_OR_2 1\n";       // (model fields are read-only after compilation: only the solver options change at run time)
+  }
+  {
     const char* e = std::getenv("MJB_SPEC_BAKE");                 // experiments: "off", "struct", "arrays"
     const std::string mode = e ? e : "arrays";
     if (mode != "off" && !std::getenv("MJB_SPEC_NO_BAKE"))

@@ -299,10 +299,21 @@ template <typename T> MJB_DEV void quat2mat(T* m, const T* q) {
 // sin/cos of a half joint angle.  fp32: minimax polynomials on |x| <= pi/2 (|error| < 1.5e-7, i.e. fp32 rounding level);
 // joint angles beyond +-pi fall back to the library functions.  fp64: library functions.
 MJB_DEV void half_sincos(float x, float& s, float& c) {
-  if (x > 1.5708f || x < -1.5708f) { s = sinf(x); c = cosf(x); return; }
+  // joint angles beyond +-pi: x - k pi in three exact pieces of pi (Cody-Waite), sign (-1)^k - a handful of instructions instead of
+  // the library's sinf + cosf (which inline to ~460 instructions at every call site for a branch almost never taken).  k = 0 below
+  // pi/2, so the common case is bitwise what it was; up to |x| ~ 1e4 the reduced argument is good to fp32 rounding.
+  float sgn = 1.0f;
+  if (x > 1.5708f || x < -1.5708f) {
+    const float k = rintf(x * 0.318309886f);
+    x = fmaf(-k, 3.140625f, x);
+    x = fmaf(-k, 9.67502593994140625e-4f, x);
+    x = fmaf(-k, 1.50995799097837643e-7f, x);
+    sgn = ((int)k & 1) ? -1.0f : 1.0f;
+  }
   float x2 = x * x;
   s = x * (1.0f + x2 * (-1.6666667e-1f + x2 * (8.3333310e-3f + x2 * (-1.9840874e-4f + x2 * (2.7525562e-6f + x2 * -2.3889859e-8f)))));
   c = 1.0f + x2 * (-0.5f + x2 * (4.1666668e-2f + x2 * (-1.3888889e-3f + x2 * (2.4801587e-5f + x2 * (-2.7557314e-7f + x2 * 2.0875723e-9f)))));
+  s *= sgn; c *= sgn;
 }
 MJB_DEV void half_sincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
 template <typename T> MJB_DEV void axisangle2quat(T* q, const T* axis, T angle) {
@@ -1956,9 +1967,13 @@ template <typename T> MJB_DEV void row_imp_R(T pos, T margin, const T* solimp, T
     else {
       T y;
       if (power == 1) y = x;
+#ifdef MJB_SPEC_SOLIMP_POWER_1_OR_2      // every solimp power of the baked model is 1 or 2 (checked when the kernel was specialised): no powf code
+      else y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+#else
       else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
       else if (x <= mid) y = t_pow(x, power) / t_pow(mid, power - 1);
       else y = 1 - t_pow(1 - x, power) / t_pow(1 - mid, power - 1);
+#endif
       imp = dmin + y * (dmax - dmin);
     }
   }
@@ -1975,9 +1990,13 @@ template <typename T> MJB_DEV void row_params(ModelRef<T> m, T pos, T margin, co
     else {
       T y;
       if (power == 1) y = x;
+#ifdef MJB_SPEC_SOLIMP_POWER_1_OR_2      // every solimp power of the baked model is 1 or 2 (checked when the kernel was specialised): no powf code
+      else y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+#else
       else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
       else if (x <= mid) y = t_pow(x, power) / t_pow(mid, power - 1);
       else y = 1 - t_pow(1 - x, power) / t_pow(1 - mid, power - 1);
+#endif
       imp = dmin + y * (dmax - dmin);
     }
   }
