@@ -252,6 +252,32 @@ def test_fp32_mfma_solves_at_other_matrix_sizes(n):
     measured(f"mfma_sizes/chain{n}/qvel_rel", worst_v, CHAIN_TOL32[n][2])
 
 
+def test_fp32_joint_angles_beyond_pi(world):
+    """Hinge angles far outside +-pi (the pendulum's range is +-360 rad; a spinning joint accumulates angle without bound): the fp32
+    kernel reduces the half angle by multiples of pi in three exact pieces (Cody-Waite) in front of its sin / cos polynomials instead
+    of calling the library.  Site position and one step against the float64 oracle; the bound is the fp32 resolution of the angle itself
+    (eps32 |theta| on a 0.5 m arm) plus the usual 2e-6."""
+    cm, om, dm = world("pendulum")
+    thetas = np.array([0.3, 3.0, 3.2, -3.5, 6.5, 10.0, -50.0, 100.5, 355.0, -359.9])
+    B = thetas.size
+    sim = BatchSim(dm, B, dtype="float32")
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    q32 = thetas.astype(np.float32).astype(np.float64)[:, None]              # the angle the fp32 kernel actually holds
+    sim.set("qpos", q32); sim.set("qvel", np.full((B, 1), 0.7)); sim.set("ctrl", np.zeros((B, 1)))
+    sim.debug_forward()
+    for e, od in enumerate(ods):
+        od.qpos[:] = q32[e]; od.qvel[:] = 0.7; od.ctrl[:] = 0; od.forward()
+    ref = np.stack([od.site_xpos for od in ods]).reshape(B, -1)
+    err = np.abs(sim.get("site_xpos").reshape(B, -1) - ref).max(axis=1)
+    assert (err <= 2e-6 + 0.5 * 1.2e-7 * np.abs(thetas)).all(), err
+    sim.set("qpos", q32); sim.set("qvel", np.full((B, 1), 0.7))
+    sim.step(1)
+    for od in ods:
+        od.step()
+    assert np.abs(sim.get("qpos")[:, 0] - np.array([od.qpos[0] for od in ods])).max() <= 1e-6 + 1.2e-7 * np.abs(thetas).max()
+    assert np.abs(sim.get("qvel")[:, 0] - np.array([od.qvel[0] for od in ods])).max() <= 2e-5
+
+
 @pytest.mark.parametrize("name,steps", [("pendulum", 100), ("cartpole", 100), ("drone2", 100), ("humanoid", 100), ("base", 100)])
 def test_fp32_teacher_forced_single_step(world, name, steps):
     """fp32 product path from identical states (teacher-forced along the oracle trajectory): one-step |dqpos| and

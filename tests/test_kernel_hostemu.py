@@ -230,3 +230,16 @@ def test_fp32_mfma_solves_at_other_matrix_sizes_on_the_cpu(n):
         od.step(); e.step()
         assert np.abs(e.qpos - od.qpos).max() < 2e-7 and np.abs(e.qvel - od.qvel).max() < 4e-5
     assert worst < 6e-4                                                  # measured 1.4e-4 (n = 32), 8.5e-5 (n = 30)
+
+
+def test_fp32_joint_angles_beyond_pi_on_the_cpu(compiled):
+    """The half-angle reduction by multiples of pi (three exact pieces, in front of the fp32 sin / cos polynomials) at hinge angles far
+    outside +-pi: emulated kernel against the float64 oracle on the pendulum's site position."""
+    cm = compiled("pendulum")
+    od = mjo.OracleData(mjo.OracleModel(cm))
+    e = EmuEnv(cm, G=8, use_double=False)
+    for theta in (3.2, -3.5, 10.0, -50.0, 100.5, 355.0):
+        t32 = float(np.float32(theta))
+        od.qpos[:] = t32; od.qvel[:] = 0; od.forward()
+        e.qpos[:] = t32; e.qvel[:] = 0; e.forward()
+        assert np.abs(e.site_xpos.ravel() - od.site_xpos.ravel()).max() <= 2e-6 + 0.5 * 1.2e-7 * abs(theta), theta
