@@ -252,6 +252,32 @@ def test_fp32_mfma_solves_at_other_matrix_sizes(n):
     measured(f"mfma_sizes/chain{n}/qvel_rel", worst_v, CHAIN_TOL32[n][2])
 
 
+def test_solimp_power_other_than_two_keeps_the_pow_path():
+    """A joint limit with solimp power 3: the specialised kernel of THAT model is generated with the powf branch (tests/test_abi.py
+    checks the switch), equals the generic kernel bit for bit and matches the oracle's impedance at the active limit."""
+    cubic = BASE_XML.replace('<joint limited="true" range="-1 1"/>', '<joint limited="true" range="-1 1" solimplimit="0.9 0.95 0.001 0.5 3"/>')
+    cm = mjcf.compile_xml_string(cubic)
+    om, dm = mjo.OracleModel(cm), DeviceModel(cm)
+    B = 8
+    q = np.linspace(0.9993, 1.0009, B)[:, None]                          # through the limit's impedance width (0.001) at the upper bound
+    ods = [mjo.OracleData(om) for _ in range(B)]
+    spec, gen = BatchSim(dm, B, dtype="float32"), BatchSim(dm, B, dtype="float32", specialize=False)
+    assert spec.specialized and not gen.specialized
+    for x in (spec, gen):
+        x.set("qpos", q); x.set("qvel", np.full((B, 1), 0.3)); x.set("ctrl", np.zeros((B, cm.nu)))
+        x.debug_forward()
+    for e, od in enumerate(ods):
+        od.qpos[:] = q[e]; od.qvel[:] = 0.3; od.ctrl[:] = 0; od.forward()
+    assert sum(od.counters()["nefc"] for od in ods) >= 3
+    assert np.array_equal(spec.get("qacc"), gen.get("qacc")) and np.array_equal(spec.debug_get("efc_D"), gen.debug_get("efc_D"))
+    for e, od in enumerate(ods):
+        n = od.counters()["nefc"]
+        if n:
+            assert np.abs(spec.debug_get("efc_D")[e, :n] - od.efc_D).max() <= 2e-4 * np.abs(od.efc_D).max()
+    ref = np.stack([od.qacc for od in ods])
+    assert np.abs(spec.get("qacc") - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_fp32_joint_angles_beyond_pi(world):
     """Hinge angles far outside +-pi (the pendulum's range is +-360 rad; a spinning joint accumulates angle without bound): the fp32
     kernel reduces the half angle by multiples of pi in three exact pieces (Cody-Waite) in front of its sin / cos polynomials instead
